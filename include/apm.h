@@ -1,0 +1,176 @@
+/*
+ * include/apm.h -- C ABI of the MI355X approximate-pattern-matching engine.
+ *
+ * This is the drop-in boundary for ONE path of
+ * linomp/INF560-approximate-pattern-matching: the Levenshtein sliding-window
+ * DP + per-pattern match count
+ *     levenshtein()                    /root/reference/src/utils.c:76-99
+ *     per-pattern scan loop            /root/reference/src/sequential.c:105-144
+ * and it replaces the reference's hand-declared extern "C" GPU shim
+ *     getDeviceCount / setDevice       src/cuda_utils.cu:10-35
+ *     invoke_kernel / write_kernel_result   src/patterns_over_ranks.cu:75-134
+ *     initializeGPU / getGPUResult     src/database_over_ranks.cu:137-205
+ * (prototypes re-declared at src/main.c:18-19, src/patterns_over_ranks.c:33-36,
+ *  src/database_over_ranks.c:18-22).
+ *
+ * Conventions
+ *   - plain C linkage, pointers + sizes only, no C++/torch types;
+ *   - every function returns APM_OK (0) or a negative apm_status and NEVER
+ *     calls exit(); apm_last_error() gives the message;
+ *   - the library owns all device memory it allocates; caller buffers are
+ *     borrowed for the duration of the call;
+ *   - counts are uint64 (the reference uses int, src/sequential.c:32); values
+ *     are identical whenever they fit in int;
+ *   - one apm_ctx per host thread (thread-compatible, not thread-safe);
+ *   - there is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with APM_ERR_NO_DEVICE.
+ *
+ * Semantics (pinned by tests/golden/golden.json, produced by the reference):
+ *   counts[i] = #{ j in [0, n-k) : dist(pattern_i[0:size], text[j:j+size]) <= k },
+ *   size = min(m_i, n-j), dist = square global unit-cost Levenshtein distance,
+ *   bytes compared verbatim (newlines are ordinary bytes).
+ */
+#ifndef APM_H
+#define APM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APM_ABI_VERSION 1
+
+typedef enum apm_status {
+    APM_OK = 0,
+    APM_ERR_INVALID = -1,     /* bad argument (NULL, negative k, empty pattern ...) */
+    APM_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range */
+    APM_ERR_HIP = -3,         /* a HIP runtime call failed */
+    APM_ERR_IO = -4,          /* open/read failed (apm_count_file) */
+    APM_ERR_NOMEM = -5,
+    APM_ERR_UNSUPPORTED = -6, /* e.g. pattern longer than APM_MAX_PATTERN_LEN,
+                                 or a kernel variant that cannot run this (m,k) */
+    APM_ERR_COMM = -7,        /* RCCL failure in single-process multi-GPU mode */
+    APM_ERR_STATE = -8        /* call order (patterns not set, ...) */
+} apm_status;
+
+/* Kernel variants.  Every variant returns the SAME exact counts; they differ
+ * in how many DP cells they really evaluate.
+ *   WAVEFRONT  full m x m DP, lanes own pattern rows, anti-diagonal sweep with
+ *              DPP/__shfl column passing (the kernel BASELINE.json names)
+ *   BITPAR     full m x m DP, one window per lane, Myers/Hyyro bit-vector
+ *              columns (32 DP cells per integer op), exact distance
+ *   BANDED     exact for the predicate dist<=k: only diagonals |x-y|<=k/2,
+ *              early exit, candidates pre-filtered by pigeonhole q-gram keys
+ *   GENERIC    literal one-column DP per lane, any m, handles truncated tails
+ *   AUTO       fastest applicable exact variant per pattern (default)        */
+typedef enum apm_kernel {
+    APM_KERNEL_AUTO = 0,
+    APM_KERNEL_GENERIC = 1,
+    APM_KERNEL_WAVEFRONT = 2,
+    APM_KERNEL_BITPAR = 3,
+    APM_KERNEL_BANDED = 4
+} apm_kernel;
+
+#define APM_MAX_PATTERN_LEN 65535
+#define APM_MAX_PATTERNS 65536
+
+typedef struct apm_ctx apm_ctx;
+
+/* Filled by the counting calls (host wall-clock + HIP-event times). */
+typedef struct apm_timing {
+    double total_ms;        /* host wall clock of the call */
+    double h2d_ms;          /* host->device copies (0 for device-resident text) */
+    double kernel_ms;       /* HIP events around all kernels of the call, max over devices */
+    double reduce_ms;       /* cross-device count reduction */
+    double main_kernel_ms;  /* HIP events around the dominant scan kernel(s) only */
+    uint64_t text_bytes;    /* bytes of text scanned (sum over devices, halos included) */
+    uint64_t windows;       /* (position, pattern) pairs decided */
+    double cells_algorithmic; /* sum over windows of size^2 (the BASELINE metric's numerator) */
+    double cells_evaluated;   /* DP cells the chosen kernels really computed (estimate for
+                                 data-dependent early exit: upper bound) */
+    int n_devices;
+    int n_launches;         /* scan-kernel launches in the call */
+} apm_timing;
+
+/* ---- device probe: replaces getDeviceCount/setDevice (src/cuda_utils.cu:10-35) ---- */
+int apm_device_count(void);                  /* >=0, or negative apm_status */
+int apm_abi_version(void);
+
+/* ---- context ---- */
+/* Single process driving devices 0..n_devices-1 (the CLI's mode): text is
+ * sharded over the devices with an (m_max-1)-byte halo and partial counts are
+ * summed with one RCCL all-reduce (falls back to a host sum of the P-vectors
+ * if librccl cannot be loaded).  n_devices<=0: all visible devices. */
+int apm_create(apm_ctx **ctx, int n_devices);
+/* One device only (the one-process-per-GPU mode used under torchrun). */
+int apm_create_on_device(apm_ctx **ctx, int device_id);
+void apm_destroy(apm_ctx *ctx);
+const char *apm_last_error(const apm_ctx *ctx); /* ctx may be NULL: last create error */
+
+/* Use an existing HIP stream (hipStream_t passed as void*) for all work of a
+ * single-device context, e.g. torch's current stream; NULL restores the
+ * context's own stream. */
+int apm_set_stream(apm_ctx *ctx, void *hip_stream);
+
+/* ---- patterns: replaces the pattern/size uploads of initializeGPU
+ *      (src/database_over_ranks.cu:157-169) and invoke_kernel (:79-94) ---- */
+/* pat[i] need not be NUL terminated; len[i] >= 1; k >= 0. */
+int apm_set_patterns(apm_ctx *ctx, int n_patterns, const char *const *pat,
+                     const int *len, int k);
+int apm_set_kernel(apm_ctx *ctx, int kernel /* apm_kernel */);
+
+/* ---- whole-text counting: replaces invoke_kernel+write_kernel_result and
+ *      initializeGPU+getGPUResult.  counts[n_patterns], host, overwritten. ---- */
+int apm_count_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *counts);
+/* 64-bit chunked file ingest (replaces read_input_file, src/utils.c:12-68). */
+int apm_count_file(apm_ctx *ctx, const char *path, uint64_t *counts);
+
+/* ---- shard-level API (device-resident text, asynchronous) ----
+ * d_text holds the bytes of global positions [text_off, text_off+text_len) on
+ * the context's device.  Counts every window whose START j lies in
+ * [own_begin, own_end) ∩ [0, n_total-k); windows running past n_total are
+ * truncated exactly as the reference does at the END OF THE WHOLE TEXT only
+ * (src/sequential.c:131-134) -- never at a shard end (that is the
+ * reference's DB_OVER_RANKS over-count, src/database_over_ranks.c:339-343).
+ * Requires text_off <= own_begin and
+ *          text_off+text_len >= min(n_total, own_end + m_max - 1).
+ * d_counts: device array of n_patterns uint64, ADDED into (caller zeroes it).
+ * Work is enqueued on the context's stream; no host synchronisation. */
+int apm_count_shard_device(apm_ctx *ctx, const void *d_text, uint64_t text_off,
+                           uint64_t text_len, uint64_t n_total,
+                           uint64_t own_begin, uint64_t own_end,
+                           uint64_t *d_counts);
+/* Owner-computes partition helper: start positions [0, max(0,n_total-k)) cut
+ * into n_shards contiguous ranges with 16-byte aligned interior boundaries. */
+int apm_shard_range(uint64_t n_total, int k, int shard, int n_shards,
+                    uint64_t *own_begin, uint64_t *own_end);
+
+/* ---- synthetic text (benchmarks): deterministic counter-based DNA ----
+ * byte i = "ACGT"[(splitmix64(seed ^ (i>>5)) >> (2*(i&31))) & 3].
+ * Device-side fill of d_dst[0:len) with global positions [global_off, +len). */
+int apm_synth_fill_device(apm_ctx *ctx, void *d_dst, uint64_t global_off,
+                          uint64_t len, uint64_t seed);
+/* Same bytes on the host (used to derive patterns without a device round trip). */
+void apm_synth_fill_host(uint8_t *dst, uint64_t global_off, uint64_t len, uint64_t seed);
+
+/* Generate n bytes on the device(s), scan them, return final counts. */
+int apm_count_synthetic(apm_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *counts);
+
+/* ---- introspection ---- */
+int apm_get_timing(const apm_ctx *ctx, apm_timing *out);
+/* Kernel variant AUTO (or the forced variant) resolves to for pattern i. */
+int apm_pattern_kernel(const apm_ctx *ctx, int i);
+/* Device memory helpers so that a C host needs no HIP headers. */
+int apm_device_alloc(apm_ctx *ctx, void **d_ptr, uint64_t bytes);
+int apm_device_free(apm_ctx *ctx, void *d_ptr);
+int apm_device_upload(apm_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+int apm_device_download(apm_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+int apm_device_memset(apm_ctx *ctx, void *d_dst, int value, uint64_t bytes);
+int apm_synchronize(apm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APM_H */
