@@ -110,8 +110,9 @@ void apm_destroy(apm_ctx *ctx);
 const char *apm_last_error(const apm_ctx *ctx); /* ctx may be NULL: last create error */
 
 /* Use an existing HIP stream (hipStream_t passed as void*) for all work of a
- * single-device context, e.g. torch's current stream; NULL restores the
- * context's own stream. */
+ * single-device context, e.g. torch's current stream.  NULL is HIP's null
+ * (legacy default) stream; APM_STREAM_OWN restores the context's own stream. */
+#define APM_STREAM_OWN ((void *)(intptr_t)-1)
 int apm_set_stream(apm_ctx *ctx, void *hip_stream);
 
 /* ---- patterns: replaces the pattern/size uploads of initializeGPU

@@ -1,0 +1,70 @@
+/*
+ * apm_internal.h -- structures shared by the runtime (apm_runtime.hip) and the
+ * kernels (apm_kernels.hip).  Not part of the ABI.
+ */
+#ifndef APM_INTERNAL_H
+#define APM_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define APM_BLOCK 256          /* threads per workgroup: 4 wave64 */
+#define APM_TILE_SLACK 320     /* bytes readable past tile+halo in LDS (ramp-down reads, 16B rounding) */
+#define APM_BITPAR_MAX_M 128
+#define APM_WAVEFRONT_MAX_M 256
+#define APM_LDS_TABLE_BUDGET (40 * 1024)
+
+/* One pattern as a scan kernel sees it. */
+struct ApmPatDesc {
+    uint32_t m;         /* length in bytes */
+    uint32_t byte_off;  /* offset of its bytes (raw, or remapped codes) in the launch's byte pool */
+    uint32_t aux_off;   /* BITPAR: offset (in uint32) of its Eq table in the launch's table pool */
+    uint32_t w;         /* BITPAR: words per column (1..4); WAVEFRONT: rows per lane R (1,2,4) */
+    uint32_t stride;    /* BITPAR: words per table entry (1,2,4) */
+    uint32_t index;     /* position in the caller's pattern list (counts[] slot) */
+};
+
+/* Arguments common to the tiled scan kernels.  All positions are RELATIVE to
+ * text[0] (= global position text_off of the shard). */
+struct ApmScanArgs {
+    const uint8_t *text;   /* device */
+    int64_t avail;         /* bytes valid at text[0..avail) */
+    int64_t jb, je;        /* window starts to decide: [jb, je), already ∩ [0, n_total-k) */
+    int64_t nrel;          /* end of the WHOLE text, relative; window j is full iff j+m <= nrel */
+    int64_t tile0;         /* base of tile 0 (<= jb, text+tile0 is 16-byte aligned) */
+    const ApmPatDesc *pats;
+    const uint8_t *bytes;  /* pattern bytes/codes pool of this launch */
+    const uint32_t *tables;/* BITPAR Eq tables of this launch */
+    const uint8_t *lut;    /* BITPAR: 256-byte text->code remap of this launch */
+    unsigned long long *counts;
+    int n_pats;
+    int k;
+    int tile;              /* window starts per workgroup */
+    int halo;              /* m_max - 1 of this launch */
+    int table_words;       /* BITPAR: total uint32 in tables */
+    int bytes_len;         /* bytes in the pattern pool */
+};
+
+struct ApmGenericArgs {
+    const uint8_t *text;
+    int64_t avail;
+    int64_t jb, je;        /* window starts [jb, je), already ∩ [0, n_total-k) */
+    int64_t nrel;
+    const ApmPatDesc *pats;/* one per blockIdx.y: m, byte_off (into bytes), index */
+    const uint8_t *bytes;  /* raw pattern bytes pool */
+    int k;
+    int mode;              /* 0: full windows only, 1: truncated tail windows only, 2: both */
+    int col_stride;        /* m_max + 1 */
+    uint16_t *scratch;     /* n_pats * col_stride * (gridDim.x*256) uint16, lane-interleaved */
+    unsigned long long *counts;
+};
+
+/* launchers (apm_kernels.hip) */
+hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s);
+hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s);
+hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s);
+hipError_t apm_launch_synth(uint8_t *dst, uint64_t global_off, uint64_t len, uint64_t seed, hipStream_t s);
+size_t apm_bitpar_lds_bytes(const ApmScanArgs &a);
+size_t apm_wavefront_lds_bytes(const ApmScanArgs &a);
+
+#endif

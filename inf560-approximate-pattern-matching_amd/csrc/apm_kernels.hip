@@ -1,0 +1,384 @@
+/*
+ * apm_kernels.hip -- CDNA4 (gfx950) kernels for the Levenshtein sliding-window
+ * DP + per-pattern match count.
+ *
+ * Path replaced (reference file:line):
+ *   levenshtein()            /root/reference/src/utils.c:76-99
+ *   per-pattern scan loop    /root/reference/src/sequential.c:105-144
+ *   (superseded GPU forms:   src/patterns_over_ranks.cu:19-73 ComputeMatches,
+ *                            src/database_over_ranks.cu:20-134 searchPattern)
+ *
+ * Common shape of the tiled scan kernels: one 256-thread workgroup owns a tile
+ * of `tile` consecutive window starts.  It stages tile+halo bytes of text from
+ * HBM into LDS with 16-byte coalesced loads ONCE, then runs every pattern of
+ * the launch over the LDS copy (1 HBM byte per text position per launch,
+ * independent of the number of patterns), reduces matches wave -> workgroup in
+ * LDS and issues one 64-bit global atomic per (workgroup, pattern) that has
+ * matches.
+ */
+#include "apm_internal.h"
+#include "apm_core.h"
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint4 apm_load16_guarded(const uint8_t *text, int64_t pos, int64_t avail) {
+    if (pos >= 0 && pos + 16 <= avail) return *reinterpret_cast<const uint4 *>(text + pos);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int64_t q = pos + b;
+        if (q >= 0 && q < avail) w[b >> 2] |= (uint32_t)text[q] << (8 * (b & 3));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t apm_wave_count(bool pred) {
+    return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred));
+}
+
+__device__ __forceinline__ int apm_min3(int a, int b, int c) { return min(min(a, b), c); }
+
+// lane l receives lane (l-1)'s value; lane 0 keeps `self` (DPP wave_shr:1, 1 VALU op)
+__device__ __forceinline__ int apm_shift_up1(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
+// ---------------------------------------------------------------------------
+// BITPAR: one window per lane, bit-vector columns (apm_core.h), exact distance.
+// The text tile is stored in LDS as CODES (byte -> small alphabet index through
+// a 256-entry LUT built from the launch's patterns; code 0 = "occurs in no
+// pattern"), so a pattern's Eq table is n_codes * stride words instead of 256.
+// ---------------------------------------------------------------------------
+template <int W, int STRIDE>
+__device__ __forceinline__ void bp_load_eq(const uint32_t *tab, uint32_t c, uint32_t (&eq)[W]) {
+    if constexpr (STRIDE == 1) {
+        eq[0] = tab[c];
+    } else if constexpr (STRIDE == 2) {
+        const uint2 v = reinterpret_cast<const uint2 *>(tab)[c];
+        eq[0] = v.x;
+        eq[1] = v.y;
+    } else {
+        const uint4 v = reinterpret_cast<const uint4 *>(tab)[c];
+        eq[0] = v.x;
+        eq[1] = v.y;
+        eq[2] = v.z;
+        if constexpr (W == 4) eq[3] = v.w;
+    }
+}
+
+template <int W, int STRIDE>
+__device__ __forceinline__ int bp_window(const uint8_t *s_tile, int joff, const uint32_t *tab, int m) {
+    uint32_t pv[W], mv[W];
+    bp_init<W>(pv, mv);
+    const uint32_t *t32 = reinterpret_cast<const uint32_t *>(s_tile + (joff & ~3));
+    const uint32_t sh = (uint32_t)joff & 3u;
+    uint32_t lo = t32[0];
+    int x = 0, q = 1;
+    for (; x + 4 <= m; x += 4, ++q) {
+        const uint32_t hi = t32[q];
+        const uint32_t w4 = __builtin_amdgcn_alignbyte(hi, lo, sh); // codes of t[j+x .. j+x+3]
+        lo = hi;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t eq[W];
+            bp_load_eq<W, STRIDE>(tab, (w4 >> (8 * b)) & 0xffu, eq);
+            bp_step<W>(pv, mv, eq);
+        }
+    }
+    if (x < m) {
+        uint32_t w4 = __builtin_amdgcn_alignbyte(t32[q], lo, sh);
+        for (; x < m; ++x) {
+            uint32_t eq[W];
+            bp_load_eq<W, STRIDE>(tab, w4 & 0xffu, eq);
+            bp_step<W>(pv, mv, eq);
+            w4 >>= 8;
+        }
+    }
+    return bp_distance<W>(pv, mv, m, m);
+}
+
+template <int W, int STRIDE>
+__device__ __forceinline__ uint32_t bp_scan(const uint8_t *s_tile, const uint32_t *tab, int m, int k,
+                                            int64_t base, int64_t jb, int64_t je_p, int tile, int tid) {
+    uint32_t cnt = 0;
+    for (int it = 0; it < tile; it += APM_BLOCK) {
+        const int joff = it + tid;
+        const int64_t j = base + joff;
+        const int dist = bp_window<W, STRIDE>(s_tile, joff, tab, m);
+        cnt += apm_wave_count(j >= jb && j < je_p && dist <= k);
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(APM_BLOCK) void apm_bitpar_kernel(ApmScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile_bytes = (a.tile + a.halo + APM_TILE_SLACK + 15) & ~15;
+    uint8_t *s_tile = smem;
+    uint8_t *s_lut = smem + tile_bytes;
+    uint32_t *s_tab = reinterpret_cast<uint32_t *>(s_lut + 256);
+    uint32_t *s_cnt = s_tab + ((a.table_words + 3) & ~3);
+    const int64_t base = a.tile0 + (int64_t)blockIdx.x * a.tile;
+
+    s_lut[tid] = a.lut[tid];
+    for (int i = tid; i < a.table_words; i += APM_BLOCK) s_tab[i] = a.tables[i];
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
+    __syncthreads();
+
+    const int nload = (a.tile + a.halo + 31) & ~15;
+    for (int i = tid * 16; i < nload; i += APM_BLOCK * 16) {
+        const uint4 v = apm_load16_guarded(a.text, base + i, a.avail);
+        const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+        uint32_t out[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            out[q] = (uint32_t)s_lut[in[q] & 0xffu] | ((uint32_t)s_lut[(in[q] >> 8) & 0xffu] << 8) |
+                     ((uint32_t)s_lut[(in[q] >> 16) & 0xffu] << 16) | ((uint32_t)s_lut[in[q] >> 24] << 24);
+        }
+        *reinterpret_cast<uint4 *>(s_tile + i) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+    __syncthreads();
+
+    for (int p = 0; p < a.n_pats; ++p) {
+        const ApmPatDesc d = a.pats[p];
+        const int m = (int)d.m;
+        const int64_t je_p = min(a.je, a.nrel - m + 1);
+        const uint32_t *tab = s_tab + d.aux_off;
+        uint32_t cnt;
+        switch (d.w) {
+        case 1: cnt = bp_scan<1, 1>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid); break;
+        case 2: cnt = bp_scan<2, 2>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid); break;
+        case 3: cnt = bp_scan<3, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid); break;
+        default: cnt = bp_scan<4, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid); break;
+        }
+        if (lane == 0 && cnt) atomicAdd(&s_cnt[p], cnt);
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
+        const uint32_t c = s_cnt[i];
+        if (c) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)c);
+    }
+}
+
+size_t apm_bitpar_lds_bytes(const ApmScanArgs &a) {
+    const size_t tile_bytes = (size_t)((a.tile + a.halo + APM_TILE_SLACK + 15) & ~15);
+    return tile_bytes + 256 + (size_t)((a.table_words + 3) & ~3) * 4 + (size_t)a.n_pats * 4 + 16;
+}
+
+hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s) {
+    const int64_t span = a.je - a.tile0;
+    if (span <= 0 || a.n_pats <= 0) return hipSuccess;
+    const int64_t nt = (span + a.tile - 1) / a.tile;
+    if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(apm_bitpar_kernel, dim3((unsigned)nt), dim3(APM_BLOCK), apm_bitpar_lds_bytes(a), s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// WAVEFRONT: the anti-diagonal kernel BASELINE.json's north_star names.
+//
+// A pattern of m rows is laid over Lm = ceil(m/R) lanes (R rows per lane);
+// S = 64/Lm windows ("streams") sit side by side in one wave64 and advance in
+// lockstep.  At step s the lane holding rows r0+1..r0+R works on text column
+// x = s - y0 + 1 (y0 = its index inside the stream): the anti-diagonal.  The
+// value cell(x, r0) it needs from the lane above was produced one step earlier
+// and arrives through one DPP wave_shr:1 move (the "__shfl_up column passing");
+// cell(x-1, r0) is last step's arrival.  All values are kept "+1" so that a
+// cell costs v_cmp_eq, v_subb, v_min3, v_add.  Ramp-up (s < y0) is exec-masked;
+// ramp-down garbage never flows back up.  The last lane of a stream finishes
+// cell(m,m) exactly at the last step, m + Lm - 2.
+// ---------------------------------------------------------------------------
+template <int R>
+__device__ __forceinline__ uint32_t wf_scan(const uint8_t *s_tile, const uint8_t *s_pat, int m, int k,
+                                            int64_t base, int64_t jb, int64_t je_p, int tile, int wave, int lane) {
+    const int Lm = (m + R - 1) / R;
+    const int S = 64 / Lm;
+    const int sig = lane / Lm;
+    const int y0 = lane - sig * Lm;
+    const bool live = sig < S;
+    const int r0 = y0 * R;
+    int pch[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) pch[i] = (r0 + i < m) ? (int)s_pat[r0 + i] : (0x100 + i);
+    const bool row0 = (y0 == 0);
+    const bool is_res = live && (y0 == Lm - 1);
+    const int ires = (m - 1) - (Lm - 1) * R;
+    const int nsteps = m + Lm - 1;
+    uint32_t cnt = 0;
+
+    for (int g0 = wave * S; g0 < tile; g0 += (APM_BLOCK / 64) * S) {
+        const int joff = live ? g0 + sig : g0; // idle lanes shadow stream 0, never counted
+        int cp1[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) cp1[i] = r0 + i + 2; // cell(0, r0+i+1) + 1
+        int upprev = r0 + 1;                             // cell(0, r0) + 1
+        const int cidx = joff - y0;
+
+        auto step = [&](int s, int recv) {
+            const int x = s - y0 + 1;
+            int up = row0 ? x + 1 : recv; // cell(x, r0) + 1
+            int dg = row0 ? x : upprev;   // cell(x-1, r0) + 1
+            upprev = up;
+            const int tch = (int)s_tile[cidx + s];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int left = cp1[i];                  // cell(x-1, r) + 1
+                const int t = dg - (tch == pch[i] ? 1 : 0); // cell(x-1, r-1) + neq
+                const int v = apm_min3(left, up, t);      // cell(x, r)
+                dg = left;
+                up = v + 1;
+                cp1[i] = up;
+            }
+        };
+
+        int s = 0;
+        for (; s < Lm - 1; ++s) { // ramp-up: lanes join one per step
+            const int recv = apm_shift_up1(cp1[R - 1]);
+            if (s >= y0) step(s, recv);
+        }
+        for (; s < nsteps; ++s) {
+            const int recv = apm_shift_up1(cp1[R - 1]);
+            step(s, recv);
+        }
+
+        int resp1 = cp1[0];
+#pragma unroll
+        for (int i = 1; i < R; ++i)
+            if (i == ires) resp1 = cp1[i];
+        const int64_t j = base + joff;
+        cnt += apm_wave_count(is_res && joff < tile && j >= jb && j < je_p && resp1 <= k + 1);
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(APM_BLOCK) void apm_wavefront_kernel(ApmScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile_bytes = (a.tile + a.halo + APM_TILE_SLACK + 15) & ~15;
+    uint8_t *s_tile = smem;
+    uint8_t *s_pat = smem + tile_bytes;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_pat + ((a.bytes_len + 15) & ~15));
+    const int64_t base = a.tile0 + (int64_t)blockIdx.x * a.tile;
+
+    for (int i = tid; i < a.bytes_len; i += APM_BLOCK) s_pat[i] = a.bytes[i];
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
+    const int nload = (a.tile + a.halo + 31) & ~15;
+    for (int i = tid * 16; i < nload; i += APM_BLOCK * 16)
+        *reinterpret_cast<uint4 *>(s_tile + i) = apm_load16_guarded(a.text, base + i, a.avail);
+    __syncthreads();
+
+    for (int p = 0; p < a.n_pats; ++p) {
+        const ApmPatDesc d = a.pats[p];
+        const int m = (int)d.m;
+        const int64_t je_p = min(a.je, a.nrel - m + 1);
+        const uint8_t *pat = s_pat + d.byte_off;
+        uint32_t cnt;
+        switch (d.w) {
+        case 1: cnt = wf_scan<1>(s_tile, pat, m, a.k, base, a.jb, je_p, a.tile, wave, lane); break;
+        case 2: cnt = wf_scan<2>(s_tile, pat, m, a.k, base, a.jb, je_p, a.tile, wave, lane); break;
+        default: cnt = wf_scan<4>(s_tile, pat, m, a.k, base, a.jb, je_p, a.tile, wave, lane); break;
+        }
+        if (lane == 0 && cnt) atomicAdd(&s_cnt[p], cnt);
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
+        const uint32_t c = s_cnt[i];
+        if (c) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)c);
+    }
+}
+
+size_t apm_wavefront_lds_bytes(const ApmScanArgs &a) {
+    const size_t tile_bytes = (size_t)((a.tile + a.halo + APM_TILE_SLACK + 15) & ~15);
+    return tile_bytes + (size_t)((a.bytes_len + 15) & ~15) + (size_t)a.n_pats * 4 + 16;
+}
+
+hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s) {
+    const int64_t span = a.je - a.tile0;
+    if (span <= 0 || a.n_pats <= 0) return hipSuccess;
+    const int64_t nt = (span + a.tile - 1) / a.tile;
+    if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(apm_wavefront_kernel, dim3((unsigned)nt), dim3(APM_BLOCK), apm_wavefront_lds_bytes(a), s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// GENERIC: literal one-column DP per lane (the loop of utils.c:84-97 with the
+// column in a per-thread slice of global scratch, interleaved so that lanes
+// touch consecutive addresses).  Any m <= 65535; applies the end-of-text
+// truncation of sequential.c:131-134.  Used for the <= m-1 truncated tail
+// windows of every pattern and for patterns too long for the tiled kernels.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(APM_BLOCK) void apm_generic_kernel(ApmGenericArgs a) {
+    const ApmPatDesc d = a.pats[blockIdx.y];
+    const int m = (int)d.m;
+    const uint8_t *pat = a.bytes + d.byte_off;
+    const int64_t nthreads = (int64_t)gridDim.x * APM_BLOCK;
+    const int64_t gtid = (int64_t)blockIdx.x * APM_BLOCK + threadIdx.x;
+    uint16_t *col = a.scratch + (int64_t)blockIdx.y * a.col_stride * nthreads + gtid;
+    const int64_t first_trunc = a.nrel - m + 1; // first window start that runs past the end of the text
+    int64_t jb = a.jb, je = a.je;
+    if (a.mode == 0) je = min(je, first_trunc);
+    if (a.mode == 1) jb = max(jb, first_trunc);
+    uint32_t cnt = 0;
+    const int64_t span = je - jb;
+    const int64_t rounds = span > 0 ? (span + nthreads - 1) / nthreads : 0;
+    for (int64_t r = 0; r < rounds; ++r) {
+        const int64_t j = jb + r * nthreads + gtid;
+        bool hit = false;
+        if (j < je) {
+            const int64_t rem = a.nrel - j;
+            const int size = rem < (int64_t)m ? (int)rem : m; // sequential.c:131-134
+            for (int y = 0; y <= size; ++y) col[(int64_t)y * nthreads] = (uint16_t)y;
+            for (int x = 1; x <= size; ++x) {
+                const uint8_t tc = a.text[j + x - 1];
+                int diag = x - 1;
+                int up = x;
+                col[0] = (uint16_t)x;
+                for (int y = 1; y <= size; ++y) {
+                    const int left = col[(int64_t)y * nthreads];
+                    const int v = apm_min3(left + 1, up + 1, diag + (pat[y - 1] != tc ? 1 : 0));
+                    col[(int64_t)y * nthreads] = (uint16_t)v;
+                    diag = left;
+                    up = v;
+                }
+            }
+            hit = (int)col[(int64_t)size * nthreads] <= a.k;
+        }
+        cnt += apm_wave_count(hit);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
+}
+
+hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s) {
+    if (a.je <= a.jb || n_pats <= 0) return hipSuccess;
+    hipLaunchKernelGGL(apm_generic_kernel, dim3((unsigned)nbx, (unsigned)n_pats), dim3(APM_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// synthetic text fill: 16 bytes per lane, 16-byte stores
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(APM_BLOCK) void apm_synth_kernel(uint8_t *dst, uint64_t global_off, uint64_t len,
+                                                             uint64_t seed) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * APM_BLOCK;
+    for (uint64_t t = (uint64_t)blockIdx.x * APM_BLOCK + threadIdx.x; t * 16 < len; t += nthreads) {
+        const uint64_t o = t * 16;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int b = 0; b < 16; ++b) w[b >> 2] |= (uint32_t)apm_synth_byte(global_off + o + b, seed) << (8 * (b & 3));
+        if (o + 16 <= len && ((reinterpret_cast<uintptr_t>(dst + o) & 15u) == 0)) {
+            *reinterpret_cast<uint4 *>(dst + o) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int b = 0; o + b < len; ++b) dst[o + b] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
+hipError_t apm_launch_synth(uint8_t *dst, uint64_t global_off, uint64_t len, uint64_t seed, hipStream_t s) {
+    if (len == 0) return hipSuccess;
+    uint64_t nb = (len / 16 + APM_BLOCK - 1) / APM_BLOCK + 1;
+    if (nb > 256 * 32) nb = 256 * 32;
+    hipLaunchKernelGGL(apm_synth_kernel, dim3((unsigned)nb), dim3(APM_BLOCK), 0, s, dst, global_off, len, seed);
+    return hipGetLastError();
+}

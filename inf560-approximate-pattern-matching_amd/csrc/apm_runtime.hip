@@ -1,0 +1,963 @@
+/*
+ * apm_runtime.hip -- implementation of the C ABI in include/apm.h.
+ *
+ * Host-side replacement for the reference's dispatch layer around its GPU shim:
+ *   MPI master/worker + shard bounds   /root/reference/src/database_over_ranks.c:141-195
+ *   GPU shims                          /root/reference/src/*.cu (see include/apm.h)
+ * Design: owner-computes text sharding with an (m_max-1)-byte halo, truncation
+ * only at the end of the WHOLE text, counts summed with one RCCL
+ * all-reduce (single-process mode) or by the caller's collective
+ * (one-process-per-GPU mode: apm_count_shard_device + torch.distributed).
+ *
+ * There is no CPU fallback in this file by design.
+ */
+#include "../../include/apm.h"
+#include "apm_internal.h"
+#include "apm_core.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+// --------------------------------------------------------------------------
+// internal kernels defined here (tiny)
+// --------------------------------------------------------------------------
+__global__ void apm_add_const_kernel(unsigned long long *counts, int idx, unsigned long long v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counts[idx], v);
+}
+
+namespace {
+
+thread_local std::string g_create_error;
+
+using clk = std::chrono::steady_clock;
+double ms_since(clk::time_point t0) {
+    return std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+}
+
+struct PatternInfo {
+    std::string bytes;
+    int m = 0;
+    int kernel = APM_KERNEL_BITPAR; // resolved variant, or -1 for "k >= m: every window matches"
+};
+constexpr int KERNEL_TRIVIAL = -1;
+
+struct TiledLaunch {       // host description of one tiled scan launch
+    int kind = 0;          // APM_KERNEL_BITPAR | APM_KERNEL_WAVEFRONT
+    std::vector<ApmPatDesc> descs;
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> tables;
+    uint8_t lut[256];
+    int m_max = 0, m_min = 0, tile = 0;
+    double cells_per_pos = 0; // sum m^2 over its patterns
+};
+
+struct GenericGroup {      // patterns scanned by the generic kernel, one launch (grid.y = pattern)
+    std::vector<ApmPatDesc> descs; // byte_off into the all-pattern pool
+    int m_max = 0;
+};
+
+struct DevTiled {
+    ApmPatDesc *d_descs = nullptr;
+    uint8_t *d_bytes = nullptr;
+    uint32_t *d_tables = nullptr;
+    uint8_t *d_lut = nullptr;
+};
+
+struct DeviceState {
+    int dev = -1;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    uint8_t *d_allpat = nullptr;              // every pattern's raw bytes, concatenated
+    ApmPatDesc *d_tail_descs = nullptr;       // all non-trivial patterns (tails)
+    ApmPatDesc *d_long_descs = nullptr;       // generic full-scan patterns
+    std::vector<DevTiled> tiled;
+    unsigned long long *d_counts = nullptr;   // P
+    uint16_t *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    uint8_t *d_text = nullptr;
+    size_t text_cap = 0;
+    hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
+    bool events_recorded = false;
+    // per-call accounting
+    uint64_t text_bytes = 0;
+    int launches = 0;
+};
+
+struct RcclApi {
+    void *handle = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    std::vector<void *> comms;
+    bool ready = false;
+};
+
+} // namespace
+
+struct apm_ctx {
+    std::vector<DeviceState> devs;
+    std::vector<PatternInfo> pats;
+    std::vector<TiledLaunch> tiled;
+    GenericGroup tails;   // every non-trivial pattern
+    GenericGroup longs;   // patterns scanned fully by the generic kernel
+    std::vector<int> trivial; // indices with k >= m
+    std::vector<uint8_t> allpat;
+    int k = 0;
+    int kernel = APM_KERNEL_AUTO;
+    int m_max = 0; // over non-trivial patterns
+    bool patterns_set = false;
+    std::string err;
+    apm_timing timing{};
+    RcclApi rccl;
+    bool multi = false; // created by apm_create (single process, >=1 devices)
+};
+
+namespace {
+
+int fail(apm_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(ctx, APM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// plan: which kernel scans which pattern, in which launch
+// ---------------------------------------------------------------------------
+int wavefront_rows_per_lane(int m) {
+    // minimise VALU work per window: steps (m + Lm - 1) x (overhead + 4R ops) / S windows per sweep
+    int best_r = 0;
+    double best = 1e30;
+    for (int r : {1, 2, 4}) {
+        const int lm = (m + r - 1) / r;
+        if (lm > 64) continue;
+        const int s = 64 / lm;
+        const double cost = double(m + lm - 1) * (11.0 + 4.0 * r) / s;
+        if (cost < best) { best = cost; best_r = r; }
+    }
+    return best_r; // 0: does not fit (m > 256)
+}
+
+int resolve_kernel(int forced, int m, int k, std::string *why) {
+    if (forced == APM_KERNEL_AUTO) {
+        if (k >= m) return KERNEL_TRIVIAL;
+        if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR;
+        return APM_KERNEL_GENERIC;
+    }
+    switch (forced) {
+    case APM_KERNEL_GENERIC: return APM_KERNEL_GENERIC;
+    case APM_KERNEL_WAVEFRONT:
+        if (m > APM_WAVEFRONT_MAX_M) { *why = "WAVEFRONT kernel supports pattern length <= 256"; return -100; }
+        return APM_KERNEL_WAVEFRONT;
+    case APM_KERNEL_BITPAR:
+        if (m > APM_BITPAR_MAX_M) { *why = "BITPAR kernel supports pattern length <= 128"; return -100; }
+        return APM_KERNEL_BITPAR;
+    case APM_KERNEL_BANDED:
+        *why = "BANDED kernel not built into this library version";
+        return -100;
+    default: *why = "unknown kernel variant"; return -100;
+    }
+}
+
+void free_device_plan(DeviceState &ds) {
+    hipSetDevice(ds.dev);
+    for (auto &t : ds.tiled) {
+        if (t.d_descs) hipFree(t.d_descs);
+        if (t.d_bytes) hipFree(t.d_bytes);
+        if (t.d_tables) hipFree(t.d_tables);
+        if (t.d_lut) hipFree(t.d_lut);
+    }
+    ds.tiled.clear();
+    if (ds.d_allpat) hipFree(ds.d_allpat), ds.d_allpat = nullptr;
+    if (ds.d_tail_descs) hipFree(ds.d_tail_descs), ds.d_tail_descs = nullptr;
+    if (ds.d_long_descs) hipFree(ds.d_long_descs), ds.d_long_descs = nullptr;
+    if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
+}
+
+template <typename T>
+int upload_vec(apm_ctx *ctx, T **dptr, const std::vector<T> &v) {
+    *dptr = nullptr;
+    const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_TRY(ctx, hipMalloc((void **)dptr, bytes));
+    if (!v.empty()) HIP_TRY(ctx, hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return APM_OK;
+}
+
+int build_plan(apm_ctx *ctx) {
+    ctx->tiled.clear();
+    ctx->tails = GenericGroup();
+    ctx->longs = GenericGroup();
+    ctx->trivial.clear();
+    ctx->allpat.clear();
+    ctx->m_max = 0;
+    const int P = (int)ctx->pats.size();
+    std::vector<uint32_t> raw_off(P);
+    for (int i = 0; i < P; ++i) {
+        std::string why;
+        const int kv = resolve_kernel(ctx->kernel, ctx->pats[i].m, ctx->k, &why);
+        if (kv == -100) return fail(ctx, APM_ERR_UNSUPPORTED, "pattern %d (length %d): %s", i, ctx->pats[i].m, why.c_str());
+        ctx->pats[i].kernel = kv;
+        raw_off[i] = (uint32_t)ctx->allpat.size();
+        ctx->allpat.insert(ctx->allpat.end(), ctx->pats[i].bytes.begin(), ctx->pats[i].bytes.end());
+        if (kv == KERNEL_TRIVIAL) { ctx->trivial.push_back(i); continue; }
+        ctx->m_max = std::max(ctx->m_max, ctx->pats[i].m);
+        ApmPatDesc d{};
+        d.m = (uint32_t)ctx->pats[i].m;
+        d.byte_off = raw_off[i];
+        d.index = (uint32_t)i;
+        if (kv != APM_KERNEL_GENERIC) { // GENERIC scans truncated windows itself (mode 2)
+            ctx->tails.descs.push_back(d);
+            ctx->tails.m_max = std::max(ctx->tails.m_max, ctx->pats[i].m);
+        } else {
+            ctx->longs.descs.push_back(d);
+            ctx->longs.m_max = std::max(ctx->longs.m_max, ctx->pats[i].m);
+        }
+    }
+
+    // ---- BITPAR launches: group by LDS table budget; one text->code LUT per launch ----
+    {
+        std::vector<int> idx;
+        for (int i = 0; i < P; ++i) if (ctx->pats[i].kernel == APM_KERNEL_BITPAR) idx.push_back(i);
+        size_t pos = 0;
+        while (pos < idx.size()) {
+            TiledLaunch L;
+            L.kind = APM_KERNEL_BITPAR;
+            L.tile = 1024;
+            bool present[256] = {false};
+            int n_codes = 1; // code 0 = absent
+            size_t words = 0;
+            std::vector<int> members;
+            while (pos < idx.size() && members.size() < 1024) {
+                const PatternInfo &pi = ctx->pats[idx[pos]];
+                bool p2[256];
+                memcpy(p2, present, sizeof p2);
+                int nc = n_codes;
+                for (unsigned char c : pi.bytes) if (!p2[c]) { p2[c] = true; ++nc; }
+                const int entries = nc > 256 ? 256 : nc;
+                // every member's table is re-laid with the launch's final code count: bound with `entries`
+                size_t w_total = 0;
+                auto stride_of = [](int m) { const int w = (m + 31) / 32; return w == 3 ? 4 : w; };
+                for (int mi : members) w_total += (size_t)entries * stride_of(ctx->pats[mi].m);
+                w_total += (size_t)entries * stride_of(pi.m);
+                if (!members.empty() && w_total * 4 > APM_LDS_TABLE_BUDGET) break;
+                memcpy(present, p2, sizeof present);
+                n_codes = nc;
+                members.push_back(idx[pos]);
+                ++pos;
+                words = w_total;
+            }
+            (void)words;
+            // LUT: 256 distinct bytes => identity, no "absent" code
+            const bool full = n_codes > 256;
+            int next = 1;
+            for (int c = 0; c < 256; ++c) L.lut[c] = full ? (uint8_t)c : (present[c] ? (uint8_t)next++ : 0);
+            const int entries = full ? 256 : n_codes;
+            for (int mi : members) {
+                const PatternInfo &pi = ctx->pats[mi];
+                ApmPatDesc d{};
+                d.m = (uint32_t)pi.m;
+                d.w = (uint32_t)((pi.m + 31) / 32);
+                d.stride = d.w == 3 ? 4 : d.w;
+                d.index = (uint32_t)mi;
+                d.byte_off = 0;
+                while (L.tables.size() % 4) L.tables.push_back(0);
+                d.aux_off = (uint32_t)L.tables.size();
+                L.tables.resize(L.tables.size() + (size_t)entries * d.stride, 0u);
+                for (int y = 0; y < pi.m; ++y) {
+                    const uint32_t code = L.lut[(unsigned char)pi.bytes[y]];
+                    L.tables[d.aux_off + (size_t)code * d.stride + (y >> 5)] |= 1u << (y & 31);
+                }
+                L.descs.push_back(d);
+                L.m_max = std::max(L.m_max, pi.m);
+                L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
+                L.cells_per_pos += double(pi.m) * pi.m;
+            }
+            ctx->tiled.push_back(std::move(L));
+        }
+    }
+    // ---- WAVEFRONT launches: up to 64 patterns, raw bytes in LDS ----
+    {
+        std::vector<int> idx;
+        for (int i = 0; i < P; ++i) if (ctx->pats[i].kernel == APM_KERNEL_WAVEFRONT) idx.push_back(i);
+        for (size_t pos = 0; pos < idx.size();) {
+            TiledLaunch L;
+            L.kind = APM_KERNEL_WAVEFRONT;
+            L.tile = 512;
+            memset(L.lut, 0, sizeof L.lut);
+            for (; pos < idx.size() && L.descs.size() < 64; ++pos) {
+                const PatternInfo &pi = ctx->pats[idx[pos]];
+                ApmPatDesc d{};
+                d.m = (uint32_t)pi.m;
+                d.w = (uint32_t)wavefront_rows_per_lane(pi.m);
+                d.index = (uint32_t)idx[pos];
+                d.byte_off = (uint32_t)L.bytes.size();
+                L.bytes.insert(L.bytes.end(), pi.bytes.begin(), pi.bytes.end());
+                L.descs.push_back(d);
+                L.m_max = std::max(L.m_max, pi.m);
+                L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
+                L.cells_per_pos += double(pi.m) * pi.m;
+            }
+            ctx->tiled.push_back(std::move(L));
+        }
+    }
+
+    // ---- upload to every device ----
+    for (auto &ds : ctx->devs) {
+        free_device_plan(ds);
+        HIP_TRY(ctx, hipSetDevice(ds.dev));
+        int rc;
+        if ((rc = upload_vec(ctx, &ds.d_allpat, ctx->allpat))) return rc;
+        if ((rc = upload_vec(ctx, &ds.d_tail_descs, ctx->tails.descs))) return rc;
+        if ((rc = upload_vec(ctx, &ds.d_long_descs, ctx->longs.descs))) return rc;
+        HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
+        ds.tiled.resize(ctx->tiled.size());
+        for (size_t t = 0; t < ctx->tiled.size(); ++t) {
+            const TiledLaunch &L = ctx->tiled[t];
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_descs, L.descs))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_bytes, L.bytes))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_tables, L.tables))) return rc;
+            std::vector<uint8_t> lut(L.lut, L.lut + 256);
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_lut, lut))) return rc;
+        }
+    }
+    return APM_OK;
+}
+
+int ensure_scratch(apm_ctx *ctx, DeviceState &ds, size_t bytes) {
+    if (bytes <= ds.scratch_bytes) return APM_OK;
+    if (ds.d_scratch) {
+        HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+        hipFree(ds.d_scratch);
+        ds.d_scratch = nullptr;
+        ds.scratch_bytes = 0;
+    }
+    HIP_TRY(ctx, hipMalloc((void **)&ds.d_scratch, bytes));
+    ds.scratch_bytes = bytes;
+    return APM_OK;
+}
+
+// generic-kernel launch over a pattern group; mode 0 full windows, 1 tails only, 2 everything
+int launch_generic_group(apm_ctx *ctx, DeviceState &ds, const GenericGroup &g, const ApmPatDesc *d_descs,
+                         int mode, const uint8_t *d_text, int64_t avail, int64_t jb, int64_t je, int64_t nrel,
+                         unsigned long long *d_counts) {
+    if (g.descs.empty() || je <= jb) return APM_OK;
+    int64_t span = je - jb;
+    if (mode == 1) span = std::min<int64_t>(span, g.m_max); // at most m-1 tail windows per pattern
+    const size_t col = (size_t)g.m_max + 1;
+    const size_t budget = (size_t)1 << 30;
+    int64_t nbx = (span + APM_BLOCK - 1) / APM_BLOCK;
+    const int64_t cap = std::max<int64_t>(1, (int64_t)(budget / (col * 2 * APM_BLOCK * g.descs.size())));
+    nbx = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nbx, cap), 4096));
+    const size_t need = col * 2 * APM_BLOCK * (size_t)nbx * g.descs.size();
+    int rc = ensure_scratch(ctx, ds, need);
+    if (rc) return rc;
+    ApmGenericArgs a{};
+    a.text = d_text;
+    a.avail = avail;
+    a.jb = jb;
+    a.je = je;
+    a.nrel = nrel;
+    a.pats = d_descs;
+    a.bytes = ds.d_allpat;
+    a.k = ctx->k;
+    a.mode = mode;
+    a.col_stride = (int)col;
+    a.scratch = ds.d_scratch;
+    a.counts = d_counts;
+    HIP_TRY(ctx, apm_launch_generic(a, (int)nbx, (int)g.descs.size(), ds.stream));
+    ds.launches++;
+    return APM_OK;
+}
+
+// the shard scan proper, all on ds.stream, no host sync
+int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t text_off, uint64_t text_len,
+               uint64_t n_total, uint64_t own_begin, uint64_t own_end, unsigned long long *d_counts) {
+    const uint64_t k = (uint64_t)ctx->k;
+    const uint64_t limit = n_total > k ? n_total - k : 0;
+    const uint64_t ob = own_begin, oe = std::min(own_end, limit);
+    if (oe <= ob) return APM_OK;
+    if (text_off > ob) return fail(ctx, APM_ERR_INVALID, "shard text starts after own_begin");
+    const uint64_t m_max = (uint64_t)std::max(ctx->m_max, 1);
+    const uint64_t need_end = std::min<uint64_t>(n_total, oe + m_max - 1);
+    if (text_off + text_len < need_end)
+        return fail(ctx, APM_ERR_INVALID, "shard text too short: halo of m_max-1 = %llu bytes required",
+                    (unsigned long long)(m_max - 1));
+    HIP_TRY(ctx, hipSetDevice(ds.dev));
+    const int64_t jb = (int64_t)(ob - text_off), je = (int64_t)(oe - text_off);
+    const int64_t nrel = (int64_t)(n_total - text_off), avail = (int64_t)text_len;
+    ds.text_bytes += need_end - ob;
+
+    HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
+    for (size_t t = 0; t < ctx->tiled.size(); ++t) {
+        const TiledLaunch &L = ctx->tiled[t];
+        const int64_t je_l = std::min<int64_t>(je, nrel - L.m_min + 1);
+        if (je_l <= jb) continue;
+        ApmScanArgs a{};
+        a.text = d_text;
+        a.avail = avail;
+        a.jb = jb;
+        a.je = je_l;
+        a.nrel = nrel;
+        a.tile0 = jb - (int64_t)((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)jb) & 15u);
+        a.pats = ds.tiled[t].d_descs;
+        a.bytes = ds.tiled[t].d_bytes;
+        a.tables = ds.tiled[t].d_tables;
+        a.lut = ds.tiled[t].d_lut;
+        a.counts = d_counts;
+        a.n_pats = (int)L.descs.size();
+        a.k = ctx->k;
+        a.tile = L.tile;
+        a.halo = L.m_max - 1;
+        a.table_words = (int)L.tables.size();
+        a.bytes_len = (int)L.bytes.size();
+        if (L.kind == APM_KERNEL_BITPAR) HIP_TRY(ctx, apm_launch_bitpar(a, ds.stream));
+        else HIP_TRY(ctx, apm_launch_wavefront(a, ds.stream));
+        ds.launches++;
+    }
+    int rc = launch_generic_group(ctx, ds, ctx->longs, ds.d_long_descs, 2, d_text, avail, jb, je, nrel, d_counts);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
+    // truncated tail windows (only the shard owning the end of the text has any)
+    if (nrel - (int64_t)ctx->tails.m_max + 1 < je) {
+        rc = launch_generic_group(ctx, ds, ctx->tails, ds.d_tail_descs, 1, d_text, avail, jb, je, nrel, d_counts);
+        if (rc) return rc;
+    }
+    for (int i : ctx->trivial)
+        hipLaunchKernelGGL(apm_add_const_kernel, dim3(1), dim3(64), 0, ds.stream, d_counts, i,
+                           (unsigned long long)(oe - ob));
+    HIP_TRY(ctx, hipGetLastError());
+    return APM_OK;
+}
+
+void account(apm_ctx *ctx, uint64_t n_total, uint64_t ob, uint64_t oe) {
+    // algorithmic / evaluated cells for window starts [ob, oe) (already clipped to n-k)
+    const uint64_t k = (uint64_t)ctx->k;
+    const uint64_t limit = n_total > k ? n_total - k : 0;
+    oe = std::min(oe, limit);
+    if (oe <= ob) return;
+    for (const auto &p : ctx->pats) {
+        const uint64_t m = (uint64_t)p.m;
+        const uint64_t full_end = n_total >= m ? std::min<uint64_t>(oe, n_total - m + 1) : 0;
+        const uint64_t nfull = full_end > ob ? full_end - ob : 0;
+        double cells = double(nfull) * double(m) * double(m);
+        for (uint64_t j = std::max(ob, full_end); j < oe; ++j) { // <= m-1 truncated windows
+            const double s = double(n_total - j);
+            cells += s * s;
+        }
+        ctx->timing.windows += oe - ob;
+        ctx->timing.cells_algorithmic += cells;
+        if (p.kernel != KERNEL_TRIVIAL) ctx->timing.cells_evaluated += cells;
+    }
+}
+
+void begin_call(apm_ctx *ctx) {
+    ctx->timing = apm_timing{};
+    ctx->timing.n_devices = (int)ctx->devs.size();
+    for (auto &ds : ctx->devs) {
+        ds.text_bytes = 0;
+        ds.launches = 0;
+        ds.events_recorded = false;
+    }
+}
+
+int load_rccl(apm_ctx *ctx) {
+    RcclApi &r = ctx->rccl;
+    if (r.ready) return APM_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) return fail(ctx, APM_ERR_COMM, "cannot load librccl: %s", dlerror());
+    r.CommInitAll = (int (*)(void **, int, const int *))dlsym(r.handle, "ncclCommInitAll");
+    r.CommDestroy = (int (*)(void *))dlsym(r.handle, "ncclCommDestroy");
+    r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(r.handle, "ncclAllReduce");
+    r.GroupStart = (int (*)())dlsym(r.handle, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(r.handle, "ncclGroupEnd");
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd)
+        return fail(ctx, APM_ERR_COMM, "librccl lacks a required symbol");
+    std::vector<int> devlist;
+    for (auto &ds : ctx->devs) devlist.push_back(ds.dev);
+    r.comms.assign(ctx->devs.size(), nullptr);
+    const int rc = r.CommInitAll(r.comms.data(), (int)devlist.size(), devlist.data());
+    if (rc != 0) return fail(ctx, APM_ERR_COMM, "ncclCommInitAll failed (%d)", rc);
+    r.ready = true;
+    return APM_OK;
+}
+
+// sum the per-device partial count vectors into counts[] (host)
+int reduce_counts(apm_ctx *ctx, uint64_t *counts) {
+    const int P = (int)ctx->pats.size();
+    const auto t0 = clk::now();
+    const size_t G = ctx->devs.size();
+    bool done = false;
+    if (G > 1 && !getenv("APM_NO_RCCL")) {
+        if (load_rccl(ctx) == APM_OK) {
+            // one ncclAllReduce(sum, uint64 x P) per device, grouped (RCCL over xGMI);
+            // replaces the MPI_Send/Recv + manual sum of database_over_ranks.c:174-195
+            RcclApi &r = ctx->rccl;
+            int rc = r.GroupStart();
+            for (size_t g = 0; g < G && rc == 0; ++g) {
+                hipSetDevice(ctx->devs[g].dev);
+                rc = r.AllReduce(ctx->devs[g].d_counts, ctx->devs[g].d_counts, (size_t)P, /*ncclUint64*/ 5,
+                                 /*ncclSum*/ 0, r.comms[g], ctx->devs[g].stream);
+            }
+            if (rc == 0) rc = r.GroupEnd();
+            if (rc != 0) return fail(ctx, APM_ERR_COMM, "ncclAllReduce failed (%d)", rc);
+            HIP_TRY(ctx, hipSetDevice(ctx->devs[0].dev));
+            HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->devs[0].d_counts, (size_t)P * 8, hipMemcpyDeviceToHost,
+                                        ctx->devs[0].stream));
+            for (auto &ds : ctx->devs) {
+                HIP_TRY(ctx, hipSetDevice(ds.dev));
+                HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+            }
+            done = true;
+        }
+    }
+    if (!done) {
+        std::vector<uint64_t> tmp((size_t)P);
+        for (int i = 0; i < P; ++i) counts[i] = 0;
+        for (auto &ds : ctx->devs) {
+            HIP_TRY(ctx, hipSetDevice(ds.dev));
+            HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ds.d_counts, (size_t)P * 8, hipMemcpyDeviceToHost, ds.stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+            for (int i = 0; i < P; ++i) counts[i] += tmp[i];
+        }
+    }
+    ctx->timing.reduce_ms = ms_since(t0);
+    return APM_OK;
+}
+
+int collect_event_times(apm_ctx *ctx) {
+    double kmax = 0, mmax = 0, hmax = 0;
+    uint64_t bytes = 0;
+    int launches = 0;
+    for (auto &ds : ctx->devs) {
+        bytes += ds.text_bytes;
+        launches += ds.launches;
+        if (!ds.events_recorded) continue;
+        HIP_TRY(ctx, hipSetDevice(ds.dev));
+        HIP_TRY(ctx, hipEventSynchronize(ds.ev_stop));
+        float h = 0, kk = 0, mm = 0;
+        hipEventElapsedTime(&h, ds.ev_start, ds.ev_kstart);
+        hipEventElapsedTime(&kk, ds.ev_kstart, ds.ev_stop);
+        if (hipEventElapsedTime(&mm, ds.ev_mstart, ds.ev_mstop) != hipSuccess) mm = 0;
+        hmax = std::max<double>(hmax, h);
+        kmax = std::max<double>(kmax, kk);
+        mmax = std::max<double>(mmax, mm);
+    }
+    ctx->timing.h2d_ms = hmax;
+    ctx->timing.kernel_ms = kmax;
+    ctx->timing.main_kernel_ms = mmax;
+    ctx->timing.text_bytes = bytes;
+    ctx->timing.n_launches = launches;
+    return APM_OK;
+}
+
+int ensure_text(apm_ctx *ctx, DeviceState &ds, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes <= ds.text_cap) return APM_OK;
+    HIP_TRY(ctx, hipSetDevice(ds.dev));
+    if (ds.d_text) {
+        HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+        hipFree(ds.d_text);
+        ds.d_text = nullptr;
+        ds.text_cap = 0;
+    }
+    HIP_TRY(ctx, hipMalloc((void **)&ds.d_text, bytes));
+    ds.text_cap = bytes;
+    return APM_OK;
+}
+
+int init_device(apm_ctx *ctx, DeviceState &ds, int dev) {
+    ds.dev = dev;
+    HIP_TRY(ctx, hipSetDevice(dev));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ds.own_stream, hipStreamNonBlocking));
+    ds.stream = ds.own_stream;
+    HIP_TRY(ctx, hipEventCreate(&ds.ev_start));
+    HIP_TRY(ctx, hipEventCreate(&ds.ev_kstart));
+    HIP_TRY(ctx, hipEventCreate(&ds.ev_mstart));
+    HIP_TRY(ctx, hipEventCreate(&ds.ev_mstop));
+    HIP_TRY(ctx, hipEventCreate(&ds.ev_stop));
+    return APM_OK;
+}
+
+// the three host-level entry points share this: `stage(g, ds, lo, len)` must enqueue the
+// bytes of global positions [lo, lo+len) into ds.d_text on ds.stream.
+template <typename Stage>
+int count_sharded(apm_ctx *ctx, uint64_t n, uint64_t *counts, Stage stage) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (!ctx->patterns_set) return fail(ctx, APM_ERR_STATE, "apm_set_patterns has not been called");
+    if (!counts) return fail(ctx, APM_ERR_INVALID, "counts is NULL");
+    const auto t0 = clk::now();
+    begin_call(ctx);
+    const int G = (int)ctx->devs.size();
+    const int P = (int)ctx->pats.size();
+    const uint64_t halo = (uint64_t)std::max(ctx->m_max, 1) - 1;
+    for (int g = 0; g < G; ++g) {
+        DeviceState &ds = ctx->devs[g];
+        uint64_t ob = 0, oe = 0;
+        apm_shard_range(n, ctx->k, g, G, &ob, &oe);
+        HIP_TRY(ctx, hipSetDevice(ds.dev));
+        HIP_TRY(ctx, hipEventRecord(ds.ev_start, ds.stream));
+        HIP_TRY(ctx, hipMemsetAsync(ds.d_counts, 0, std::max<size_t>((size_t)P * 8, 16), ds.stream));
+        const uint64_t lo = ob, hi = std::min<uint64_t>(n, oe + halo);
+        const uint64_t len = hi > lo ? hi - lo : 0;
+        if (oe > ob) {
+            int rc = ensure_text(ctx, ds, (size_t)len + 16);
+            if (rc) return rc;
+            rc = stage(g, ds, lo, len);
+            if (rc) return rc;
+        }
+        HIP_TRY(ctx, hipEventRecord(ds.ev_kstart, ds.stream));
+        if (oe > ob) {
+            int rc = scan_shard(ctx, ds, ds.d_text, lo, len, n, ob, oe, ds.d_counts);
+            if (rc) return rc;
+            account(ctx, n, ob, oe);
+        } else {
+            HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
+            HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
+        }
+        HIP_TRY(ctx, hipEventRecord(ds.ev_stop, ds.stream));
+        ds.events_recorded = true;
+    }
+    int rc = reduce_counts(ctx, counts);
+    if (rc) return rc;
+    rc = collect_event_times(ctx);
+    if (rc) return rc;
+    ctx->timing.total_ms = ms_since(t0);
+    return APM_OK;
+}
+
+} // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int apm_abi_version(void) { return APM_ABI_VERSION; }
+
+int apm_device_count(void) {
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e);
+        return APM_ERR_HIP;
+    }
+    return n;
+}
+
+const char *apm_last_error(const apm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+static int create_common(apm_ctx **out, const std::vector<int> &devs, bool multi) {
+    apm_ctx *ctx = new (std::nothrow) apm_ctx();
+    if (!ctx) return fail(nullptr, APM_ERR_NOMEM, "out of memory");
+    ctx->multi = multi;
+    ctx->devs.resize(devs.size());
+    for (size_t i = 0; i < devs.size(); ++i) {
+        const int rc = init_device(ctx, ctx->devs[i], devs[i]);
+        if (rc) {
+            g_create_error = ctx->err;
+            apm_destroy(ctx);
+            return rc;
+        }
+    }
+    *out = ctx;
+    return APM_OK;
+}
+
+int apm_create(apm_ctx **ctx, int n_devices) {
+    if (!ctx) return fail(nullptr, APM_ERR_INVALID, "ctx is NULL");
+    *ctx = nullptr;
+    const int have = apm_device_count();
+    if (have < 0) return have;
+    if (have == 0) return fail(nullptr, APM_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    if (n_devices <= 0) n_devices = have;
+    if (n_devices > have) return fail(nullptr, APM_ERR_NO_DEVICE, "%d devices requested, %d visible", n_devices, have);
+    std::vector<int> devs;
+    for (int i = 0; i < n_devices; ++i) devs.push_back(i);
+    return create_common(ctx, devs, true);
+}
+
+int apm_create_on_device(apm_ctx **ctx, int device_id) {
+    if (!ctx) return fail(nullptr, APM_ERR_INVALID, "ctx is NULL");
+    *ctx = nullptr;
+    const int have = apm_device_count();
+    if (have < 0) return have;
+    if (have == 0) return fail(nullptr, APM_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    if (device_id < 0 || device_id >= have)
+        return fail(nullptr, APM_ERR_NO_DEVICE, "device %d out of range (%d visible)", device_id, have);
+    return create_common(ctx, std::vector<int>{device_id}, false);
+}
+
+void apm_destroy(apm_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->rccl.ready)
+        for (void *c : ctx->rccl.comms) if (c) ctx->rccl.CommDestroy(c);
+    for (auto &ds : ctx->devs) {
+        if (ds.dev < 0) continue;
+        hipSetDevice(ds.dev);
+        if (ds.own_stream) hipStreamSynchronize(ds.own_stream);
+        free_device_plan(ds);
+        if (ds.d_scratch) hipFree(ds.d_scratch);
+        if (ds.d_text) hipFree(ds.d_text);
+        for (hipEvent_t e : {ds.ev_start, ds.ev_kstart, ds.ev_mstart, ds.ev_mstop, ds.ev_stop}) if (e) hipEventDestroy(e);
+        if (ds.own_stream) hipStreamDestroy(ds.own_stream);
+    }
+    delete ctx;
+}
+
+int apm_set_stream(apm_ctx *ctx, void *hip_stream) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (ctx->devs.size() != 1) return fail(ctx, APM_ERR_STATE, "apm_set_stream needs a single-device context");
+    ctx->devs[0].stream = hip_stream == APM_STREAM_OWN ? ctx->devs[0].own_stream : (hipStream_t)hip_stream;
+    return APM_OK;
+}
+
+int apm_set_patterns(apm_ctx *ctx, int n_patterns, const char *const *pat, const int *len, int k) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (n_patterns <= 0 || n_patterns > APM_MAX_PATTERNS || !pat || !len)
+        return fail(ctx, APM_ERR_INVALID, "need 1..%d patterns", APM_MAX_PATTERNS);
+    if (k < 0) return fail(ctx, APM_ERR_INVALID, "distance must be >= 0 (the reference reads out of bounds for k<0)");
+    std::vector<PatternInfo> v((size_t)n_patterns);
+    for (int i = 0; i < n_patterns; ++i) {
+        if (!pat[i] || len[i] <= 0) return fail(ctx, APM_ERR_INVALID, "pattern %d is empty", i);
+        if (len[i] > APM_MAX_PATTERN_LEN)
+            return fail(ctx, APM_ERR_UNSUPPORTED, "pattern %d longer than %d bytes", i, APM_MAX_PATTERN_LEN);
+        v[i].bytes.assign(pat[i], pat[i] + len[i]);
+        v[i].m = len[i];
+    }
+    ctx->pats.swap(v);
+    ctx->k = k;
+    ctx->patterns_set = false;
+    const int rc = build_plan(ctx);
+    if (rc) return rc;
+    ctx->patterns_set = true;
+    return APM_OK;
+}
+
+int apm_set_kernel(apm_ctx *ctx, int kernel) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (kernel < APM_KERNEL_AUTO || kernel > APM_KERNEL_BANDED) return fail(ctx, APM_ERR_INVALID, "unknown kernel variant %d", kernel);
+    const int old = ctx->kernel;
+    ctx->kernel = kernel;
+    if (ctx->patterns_set || !ctx->pats.empty()) {
+        ctx->patterns_set = false;
+        const int rc = build_plan(ctx);
+        if (rc) {
+            const std::string msg = ctx->err;
+            ctx->kernel = old;
+            if (build_plan(ctx) == APM_OK) ctx->patterns_set = true;
+            ctx->err = msg;
+            return rc;
+        }
+        ctx->patterns_set = true;
+    }
+    return APM_OK;
+}
+
+int apm_pattern_kernel(const apm_ctx *ctx, int i) {
+    if (!ctx || i < 0 || i >= (int)ctx->pats.size()) return APM_ERR_INVALID;
+    return ctx->pats[i].kernel == KERNEL_TRIVIAL ? APM_KERNEL_AUTO : ctx->pats[i].kernel;
+}
+
+int apm_shard_range(uint64_t n_total, int k, int shard, int n_shards, uint64_t *own_begin, uint64_t *own_end) {
+    if (!own_begin || !own_end || n_shards <= 0 || shard < 0 || shard >= n_shards || k < 0) return APM_ERR_INVALID;
+    const uint64_t limit = n_total > (uint64_t)k ? n_total - (uint64_t)k : 0;
+    auto cut = [&](int s) -> uint64_t {
+        if (s <= 0) return 0;
+        if (s >= n_shards) return limit;
+        const uint64_t c = (uint64_t)((unsigned __int128)limit * (unsigned)s / (unsigned)n_shards);
+        return std::min<uint64_t>(limit, c & ~(uint64_t)15);
+    };
+    *own_begin = cut(shard);
+    *own_end = cut(shard + 1);
+    return APM_OK;
+}
+
+int apm_count_shard_device(apm_ctx *ctx, const void *d_text, uint64_t text_off, uint64_t text_len,
+                           uint64_t n_total, uint64_t own_begin, uint64_t own_end, uint64_t *d_counts) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (!ctx->patterns_set) return fail(ctx, APM_ERR_STATE, "apm_set_patterns has not been called");
+    if (ctx->devs.size() != 1) return fail(ctx, APM_ERR_STATE, "apm_count_shard_device needs a single-device context");
+    if (!d_counts || (!d_text && text_len)) return fail(ctx, APM_ERR_INVALID, "NULL device pointer");
+    if (text_off + text_len > n_total || own_begin > own_end)
+        return fail(ctx, APM_ERR_INVALID, "inconsistent shard description");
+    begin_call(ctx);
+    DeviceState &ds = ctx->devs[0];
+    HIP_TRY(ctx, hipSetDevice(ds.dev));
+    HIP_TRY(ctx, hipEventRecord(ds.ev_start, ds.stream));
+    HIP_TRY(ctx, hipEventRecord(ds.ev_kstart, ds.stream));
+    const int rc = scan_shard(ctx, ds, (const uint8_t *)d_text, text_off, text_len, n_total, own_begin, own_end,
+                              (unsigned long long *)d_counts);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ds.ev_stop, ds.stream));
+    ds.events_recorded = true;
+    account(ctx, n_total, own_begin, own_end);
+    return APM_OK;
+}
+
+int apm_count_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *counts) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (!text && n) return fail(ctx, APM_ERR_INVALID, "text is NULL");
+    // pin the caller's buffer so the per-device copies are truly asynchronous
+    bool pinned = false;
+    if (n >= (1u << 20) && ctx->devs.size() > 0)
+        pinned = hipHostRegister((void *)text, (size_t)n, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();
+    const int rc = count_sharded(ctx, n, counts, [&](int, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
+        HIP_TRY(ctx, hipMemcpyAsync(ds.d_text, text + lo, (size_t)len, hipMemcpyHostToDevice, ds.stream));
+        return APM_OK;
+    });
+    if (pinned) hipHostUnregister((void *)text);
+    return rc;
+}
+
+int apm_count_file(apm_ctx *ctx, const char *path, uint64_t *counts) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (!path) return fail(ctx, APM_ERR_INVALID, "path is NULL");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(ctx, APM_ERR_IO, "Unable to open the text file <%s>", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        close(fd);
+        return fail(ctx, APM_ERR_IO, "Unable to stat the text file <%s>", path);
+    }
+    const uint64_t n = (uint64_t)st.st_size;
+    // chunked pread into two pinned staging buffers, H2D overlapped with the next read
+    const size_t CH = (size_t)32 << 20;
+    uint8_t *stage[2] = {nullptr, nullptr};
+    hipEvent_t freed[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    int rc = APM_OK;
+    for (int b = 0; b < 2 && rc == APM_OK; ++b) {
+        if (hipHostMalloc((void **)&stage[b], CH, hipHostMallocDefault) != hipSuccess || hipEventCreate(&freed[b]) != hipSuccess)
+            rc = fail(ctx, APM_ERR_NOMEM, "cannot allocate pinned staging buffers");
+    }
+    int cur = 0;
+    if (rc == APM_OK)
+        rc = count_sharded(ctx, n, counts, [&](int, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
+            for (uint64_t off = 0; off < len;) {
+                const size_t want = (size_t)std::min<uint64_t>(CH, len - off);
+                if (used[cur]) HIP_TRY(ctx, hipEventSynchronize(freed[cur]));
+                size_t got = 0;
+                while (got < want) {
+                    const ssize_t r = pread(fd, stage[cur] + got, want - got, (off_t)(lo + off + got));
+                    if (r <= 0) return fail(ctx, APM_ERR_IO, "Unable to copy %llu byte(s) from text file", (unsigned long long)len);
+                    got += (size_t)r;
+                }
+                HIP_TRY(ctx, hipMemcpyAsync(ds.d_text + off, stage[cur], want, hipMemcpyHostToDevice, ds.stream));
+                HIP_TRY(ctx, hipEventRecord(freed[cur], ds.stream));
+                used[cur] = true;
+                cur ^= 1;
+                off += want;
+            }
+            return APM_OK;
+        });
+    for (int b = 0; b < 2; ++b) {
+        if (freed[b]) { if (used[b]) hipEventSynchronize(freed[b]); hipEventDestroy(freed[b]); }
+        if (stage[b]) hipHostFree(stage[b]);
+    }
+    close(fd);
+    return rc;
+}
+
+int apm_synth_fill_device(apm_ctx *ctx, void *d_dst, uint64_t global_off, uint64_t len, uint64_t seed) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (ctx->devs.size() != 1) return fail(ctx, APM_ERR_STATE, "apm_synth_fill_device needs a single-device context");
+    if (!d_dst && len) return fail(ctx, APM_ERR_INVALID, "NULL device pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].dev));
+    HIP_TRY(ctx, apm_launch_synth((uint8_t *)d_dst, global_off, len, seed, ctx->devs[0].stream));
+    return APM_OK;
+}
+
+void apm_synth_fill_host(uint8_t *dst, uint64_t global_off, uint64_t len, uint64_t seed) {
+    for (uint64_t i = 0; i < len; ++i) dst[i] = apm_synth_byte(global_off + i, seed);
+}
+
+int apm_count_synthetic(apm_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *counts) {
+    if (!ctx) return APM_ERR_INVALID;
+    return count_sharded(ctx, n, counts, [&](int, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
+        HIP_TRY(ctx, apm_launch_synth(ds.d_text, lo, len, seed, ds.stream));
+        return APM_OK;
+    });
+}
+
+int apm_get_timing(const apm_ctx *cctx, apm_timing *out) {
+    apm_ctx *ctx = const_cast<apm_ctx *>(cctx);
+    if (!ctx || !out) return APM_ERR_INVALID;
+    const int rc = collect_event_times(ctx);
+    if (rc) return rc;
+    *out = ctx->timing;
+    return APM_OK;
+}
+
+int apm_device_alloc(apm_ctx *ctx, void **d_ptr, uint64_t bytes) {
+    if (!ctx || !d_ptr) return APM_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].dev));
+    HIP_TRY(ctx, hipMalloc(d_ptr, (size_t)std::max<uint64_t>(bytes, 16)));
+    return APM_OK;
+}
+int apm_device_free(apm_ctx *ctx, void *d_ptr) {
+    if (!ctx) return APM_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].dev));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->devs[0].stream));
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return APM_OK;
+}
+int apm_device_upload(apm_ctx *ctx, void *d_dst, const void *src, uint64_t bytes) {
+    if (!ctx) return APM_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].dev));
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->devs[0].stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->devs[0].stream));
+    return APM_OK;
+}
+int apm_device_download(apm_ctx *ctx, void *dst, const void *d_src, uint64_t bytes) {
+    if (!ctx) return APM_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].dev));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->devs[0].stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->devs[0].stream));
+    return APM_OK;
+}
+int apm_device_memset(apm_ctx *ctx, void *d_dst, int value, uint64_t bytes) {
+    if (!ctx) return APM_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->devs[0].dev));
+    HIP_TRY(ctx, hipMemsetAsync(d_dst, value, (size_t)bytes, ctx->devs[0].stream));
+    return APM_OK;
+}
+int apm_synchronize(apm_ctx *ctx) {
+    if (!ctx) return APM_ERR_INVALID;
+    for (auto &ds : ctx->devs) {
+        HIP_TRY(ctx, hipSetDevice(ds.dev));
+        HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+    }
+    return APM_OK;
+}
+
+} // extern "C"

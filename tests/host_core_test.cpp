@@ -1,0 +1,58 @@
+// Host-side check of the arithmetic cores in csrc/apm_core.h against the oracle.
+// Built and run by tests/test_host_logic.py (g++, no GPU).
+#include "apm_core.h"
+#include "apm_oracle.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+template <int W>
+static int bp_dist(const unsigned char *p, const unsigned char *t, int m) {
+    static uint32_t peq[256][W];
+    for (int c = 0; c < 256; c++)
+        for (int w = 0; w < W; w++) peq[c][w] = 0;
+    for (int y = 0; y < m; y++) peq[p[y]][y / 32] |= 1u << (y % 32);
+    uint32_t pv[W], mv[W];
+    bp_init<W>(pv, mv);
+    for (int x = 0; x < m; x++) {
+        uint32_t eq[W];
+        for (int w = 0; w < W; w++) eq[w] = peq[t[x]][w];
+        bp_step<W>(pv, mv, eq);
+    }
+    return bp_distance<W>(pv, mv, m, m);
+}
+
+int main() {
+    srand(1);
+    int bad = 0;
+    std::vector<int> col(200);
+    for (int it = 0; it < 100000; it++) {
+        const int m = 1 + rand() % 128;
+        const int alpha = 2 + rand() % 3;
+        unsigned char p[128], t[128];
+        for (int i = 0; i < m; i++) {
+            p[i] = 'a' + rand() % alpha;
+            t[i] = (rand() % 4) ? p[i] : 'a' + rand() % alpha;
+        }
+        if (rand() % 3 == 0) {
+            const int s = rand() % 3;
+            for (int i = 0; i + s < m; i++) t[i] = p[i + s];
+        }
+        const int ref = oracle_window_distance(p, t, m, col.data());
+        const int W = (m + 31) / 32;
+        const int d = W == 1 ? bp_dist<1>(p, t, m) : W == 2 ? bp_dist<2>(p, t, m) : W == 3 ? bp_dist<3>(p, t, m) : bp_dist<4>(p, t, m);
+        const int d4 = bp_dist<4>(p, t, m);
+        if (d != ref || d4 != ref) {
+            bad++;
+            if (bad < 5) printf("m=%d ref=%d d=%d d4=%d\n", m, ref, d, d4);
+        }
+    }
+    // synthetic generator: bytes are ACGT, deterministic
+    for (uint64_t i = 0; i < 1000; i++) {
+        const uint8_t b = apm_synth_byte(i, 0x5EED0002ull);
+        if (b != 'A' && b != 'C' && b != 'G' && b != 'T') bad++;
+    }
+    printf("bad=%d\n", bad);
+    return bad != 0;
+}

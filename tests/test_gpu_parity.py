@@ -1,0 +1,324 @@
+"""GPU (-m gpu): the HIP path, called THROUGH THE C ABI, against
+  (1) the golden vectors produced by the reference binary (tests/golden),
+  (2) the oracle restatement on seeded inputs,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Bit-exact integer counts everywhere (no tolerance)."""
+import os
+import random
+import subprocess
+
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = ["auto", "bitpar", "wavefront", "generic"]
+MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 128, "wavefront": 256}
+CASES = H.golden()["cases"]
+
+
+@pytest.fixture(scope="module")
+def apm():
+    return H.pkg()
+
+
+@pytest.fixture(scope="module")
+def ctx(apm):
+    assert apm.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    c = apm.ApmContext(device=0)
+    yield c
+    c.close()
+
+
+def _run(ctx, apm, variant, patterns, k, text):
+    ctx.set_kernel("auto")
+    ctx.set_patterns(patterns, k)
+    ctx.set_kernel(variant)
+    return ctx.count_buffer(text)
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_golden(ctx, apm, case, variant):
+    pats, k = case["patterns"], case["k"]
+    if max(len(p) for p in pats) > MAX_M[variant]:
+        ctx.set_kernel("auto")
+        ctx.set_patterns(pats, k)
+        with pytest.raises(apm.ApmError) as e:      # error behaviour: UNSUPPORTED, state unchanged
+            ctx.set_kernel(variant)
+        assert e.value.status == -6
+        assert ctx.count_buffer(H.case_text(case)) == case["counts"]
+        return
+    if variant == "generic" and H.case_cells(case) > 8e9:
+        pytest.skip("literal global-memory DP: keep the GPU suite short")
+    assert _run(ctx, apm, variant, pats, k, H.case_text(case)) == case["counts"]
+
+
+def test_count_file_equals_golden(ctx):
+    for name in ("cfg1_basic_test", "x100_k3", "chrY_k5", "bigger_k0", "run_tests_easy"):
+        c = next(c for c in CASES if c["name"] == name)
+        ctx.set_kernel("auto")
+        ctx.set_patterns(c["patterns"], c["k"])
+        assert ctx.count_file(c["path"]) == c["counts"]
+
+
+# ---------------------------------------------------------------- oracle on seeded inputs
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_random_vs_oracle(ctx, apm, variant):
+    rnd = random.Random(1234)
+    for trial in range(40):
+        alpha = rnd.choice([b"ab", b"ACGT", b"ACGT\n", bytes(range(256))])
+        n = rnd.choice([0, 1, 2, 15, 16, 17, 255, 256, 257, 1023, 1024, 1025, 1500, 4095, 4097, 9000])
+        text = bytes(rnd.choice(alpha) for _ in range(n))
+        pats = []
+        for _ in range(rnd.randint(1, 7)):
+            m = rnd.choice([1, 2, 3, 4, 7, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 95, 96, 97, 127, 128])
+            if variant in ("auto", "generic", "wavefront") and rnd.random() < 0.15:
+                m = rnd.choice([129, 150, 200, 256])
+            if variant in ("auto", "generic") and rnd.random() < 0.1:
+                m = rnd.choice([257, 300, 700])
+            if n > m and rnd.random() < 0.7:
+                o = rnd.randrange(0, n - m + 1)
+                p = bytearray(text[o:o + m])
+                for _e in range(rnd.randint(0, 4)):
+                    r = rnd.random()
+                    pos = rnd.randrange(len(p))
+                    if r < 0.5:
+                        p[pos] = rnd.choice(alpha)
+                    elif r < 0.75 and len(p) > 1:
+                        del p[pos]
+                        p.append(rnd.choice(alpha))
+                    else:
+                        p.insert(pos, rnd.choice(alpha))
+                        p.pop()
+                p = bytes(p)
+            else:
+                p = bytes(rnd.choice(alpha) for _ in range(m))
+            pats.append(p)
+        k = rnd.choice([0, 0, 1, 2, 3, 4, 5, 6, 9])
+        want = H.oracle_counts(text, pats, k)
+        got = _run(ctx, apm, variant, pats, k, text)
+        assert got == want, (trial, n, k, [len(p) for p in pats])
+
+
+@pytest.mark.parametrize("variant", ["auto", "bitpar", "wavefront"])
+def test_tile_boundaries(ctx, apm, variant):
+    """a planted occurrence straddling every tile seam is found exactly once"""
+    rnd = random.Random(99)
+    n = 5000
+    base = bytearray(rnd.choice(b"ACGT") for _ in range(n))
+    pat = bytes(rnd.choice(b"ACGT") for _ in range(40))
+    for seam in (512, 1024, 2048, 3072, 4096):
+        for off in (-39, -20, -1, 0, 1):
+            text = bytearray(base)
+            o = seam + off
+            text[o:o + 40] = pat
+            text = bytes(text)
+            for k in (0, 2):
+                want = H.oracle_counts(text, [pat], k)
+                assert want[0] >= 1
+                assert _run(ctx, apm, variant, [pat], k, text) == want
+
+
+def test_duplicate_and_many_patterns(ctx, apm):
+    """P = 300 (several LDS batches) incl. duplicates -> counts[] order is argv order"""
+    rnd = random.Random(5)
+    text = bytes(rnd.choice(b"ACGT") for _ in range(6000))
+    pats = []
+    for i in range(300):
+        m = rnd.choice([8, 20, 50])
+        o = rnd.randrange(0, len(text) - m)
+        pats.append(text[o:o + m])
+    pats[17] = pats[3]
+    want = H.oracle_counts(text, pats, 1, banded=True)
+    assert _run(ctx, apm, "auto", pats, 1, text) == want
+    assert _run(ctx, apm, "wavefront", pats, 1, text) == want
+
+
+# ---------------------------------------------------------------- shards (device-resident API)
+def _device_shard_counts(ctx, text, pats, k, n_shards, front_pad=0):
+    """owner-computes partition through apm_count_shard_device; returns the summed counts"""
+    n = len(text)
+    P = len(pats)
+    apm = H.pkg()
+    m_max = max(len(p) for p in pats)
+    d_counts = ctx.device_alloc(8 * P)
+    ctx.device_memset(d_counts, 0, 8 * P)
+    for s in range(n_shards):
+        b, e = apm.shard_range(n, k, s, n_shards)
+        if e <= b:
+            continue
+        lo = max(0, b - front_pad)
+        hi = min(n, e + m_max - 1)
+        d_text = ctx.device_alloc(hi - lo + 16)
+        ctx.device_upload(d_text, text[lo:hi])
+        ctx.count_shard_device(d_text, lo, hi - lo, n, b, e, d_counts)
+        ctx.synchronize()
+        ctx.device_free(d_text)
+    raw = ctx.device_download(d_counts, 8 * P)
+    ctx.device_free(d_counts)
+    return [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(P)]
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 8])
+def test_sharded_equals_unsharded(ctx, n_shards):
+    """DB_OVER_RANKS done right: no double count at shard seams (the reference's own
+    database_over_ranks.c:339-343 over-counts there: 6 vs 3 on this very input)."""
+    ctx.set_kernel("auto")
+    text, pats = b"A" * 16, [b"AAAB", b"AAAA"]
+    ctx.set_patterns(pats, 0)
+    assert _device_shard_counts(ctx, text, pats, 0, min(n_shards, 1)) == [3, 16]
+    for name in ("chrY_k3", "x100_k2", "dna20k_k5"):
+        c = next(c for c in CASES if c["name"] == name)
+        text = H.case_text(c)
+        for variant in ("auto", "wavefront"):
+            ctx.set_kernel("auto")
+            ctx.set_patterns(c["patterns"], c["k"])
+            ctx.set_kernel(variant)
+            assert _device_shard_counts(ctx, text, c["patterns"], c["k"], n_shards) == c["counts"]
+            # text slice starting before own_begin at a non-16-byte-aligned address
+            assert _device_shard_counts(ctx, text, c["patterns"], c["k"], n_shards, front_pad=5) == c["counts"]
+
+
+def test_shard_halo_is_enforced(ctx, apm):
+    ctx.set_kernel("auto")
+    ctx.set_patterns([b"ACGTACGTAC"], 0)
+    d_text = ctx.device_alloc(64)
+    d_counts = ctx.device_alloc(8)
+    with pytest.raises(apm.ApmError) as e:       # own range [0,40) of a 100-byte text needs 49 bytes
+        ctx.count_shard_device(d_text, 0, 40, 100, 0, 40, d_counts)
+    assert e.value.status == -1
+    ctx.device_free(d_text)
+    ctx.device_free(d_counts)
+
+
+def test_argument_errors(ctx, apm):
+    with pytest.raises(apm.ApmError):
+        ctx.set_patterns([b"ACGT"], -1)
+    with pytest.raises(apm.ApmError):
+        ctx.set_patterns([b"ACGT", b""], 0)
+    with pytest.raises(apm.ApmError):
+        ctx.set_patterns([], 0)
+    with pytest.raises(apm.ApmError):
+        ctx.set_kernel(17)
+    ctx.set_patterns([b"ACGT"], 0)
+    with pytest.raises(apm.ApmError) as e:
+        ctx.count_file("/nonexistent/file.fa")
+    assert e.value.status == -4
+
+
+# ---------------------------------------------------------------- synthetic generator + workloads
+def test_device_generator_equals_host_generator(ctx, apm):
+    seed = 0x5EED0002
+    for off, ln in [(0, 4096), (48, 1000), (123456789, 777), ((1 << 33) - 4096, 4096)]:
+        d = ctx.device_alloc(ln + 16)
+        ctx.synth_fill_device(d, off, ln, seed)
+        ctx.synchronize()
+        assert ctx.device_download(d, ln) == apm.synth_fill_host(off, ln, seed)
+        ctx.device_free(d)
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg5"])
+def test_baseline_workloads_small_vs_oracle(ctx, apm, cfg):
+    """each BASELINE config's pattern set / k on a 1 MiB synthetic text: every kernel variant
+    == oracle (banded form, itself pinned to the reference on all golden cases)."""
+    wl = H.workloads()
+    c = wl.CONFIGS[cfg]
+    n = 1 << 20
+    seed = wl.seed_of(c["cid"])
+    lens = c["lens"] if cfg != "cfg5" else c["lens"][:48]
+    pats, planted = wl.make_patterns(n, lens, c["k"], seed)
+    text = apm.synth_fill_host(0, n, seed)
+    want = H.oracle_counts(text, pats, c["k"], banded=True)
+    for (o, d), w in zip(planted, want):
+        assert (w >= 1) or d > c["k"]
+    for variant in ("auto", "bitpar", "wavefront"):
+        ctx.set_kernel("auto")
+        ctx.set_patterns(pats, c["k"])
+        ctx.set_kernel(variant)
+        assert ctx.count_synthetic(n, seed) == want, variant
+
+
+def test_cfg2_full_size_properties(ctx, apm):
+    """BASELINE cfg2 at FULL size (256 MiB, 8x32, k=0): planted exact copies are found,
+    kernel variants agree bit for bit, and an 8-way shard sum equals the whole."""
+    wl = H.workloads()
+    c = wl.CONFIGS["cfg2"]
+    n, k, seed = c["n"], c["k"], wl.seed_of(c["cid"])
+    pats, planted = wl.make_patterns(n, c["lens"], k, seed)
+    ctx.set_kernel("auto")
+    ctx.set_patterns(pats, k)
+    auto = ctx.count_synthetic(n, seed)
+    for (o, d), cnt in zip(planted, auto):
+        assert cnt == (1 if d == 0 else 0)       # a random 32-mer recurs with p ~ 2^-36
+    ctx.set_kernel("bitpar")
+    assert ctx.count_synthetic(n, seed) == auto
+    # CPU slice check: first 256 KiB by the oracle (literal DP)
+    sl = 1 << 18
+    text = apm.synth_fill_host(0, sl + 31, seed)
+    want = H.oracle_counts(text, pats, k, j_end=sl)
+    ctx.set_kernel("auto")
+    d_text = ctx.device_alloc(len(text) + 16)
+    d_counts = ctx.device_alloc(64)
+    ctx.device_upload(d_text, text)
+    ctx.device_memset(d_counts, 0, 64)
+    ctx.count_shard_device(d_text, 0, len(text), n, 0, sl, d_counts)
+    ctx.synchronize()
+    raw = ctx.device_download(d_counts, 64)
+    assert [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(8)] == want
+    ctx.device_free(d_text)
+    ctx.device_free(d_counts)
+
+
+def test_cfg3_4mib_vs_oracle(ctx, apm):
+    """cfg3's pattern set (32 patterns, m = 16..128, k = 3) on 4 MiB against the banded oracle."""
+    wl = H.workloads()
+    c = wl.CONFIGS["cfg3"]
+    n, k, seed = 1 << 22, c["k"], wl.seed_of(c["cid"])
+    pats, planted = wl.make_patterns(n, c["lens"], k, seed)
+    text = apm.synth_fill_host(0, n, seed)
+    want = H.oracle_counts(text, pats, k, banded=True)
+    ctx.set_kernel("auto")
+    ctx.set_patterns(pats, k)
+    assert ctx.count_synthetic(n, seed) == want
+    assert ctx.count_buffer(text) == want
+
+
+# ---------------------------------------------------------------- the C host (reference CLI contract)
+CLI = os.path.join(H.PKG_DIR, "host", "apm_parallel")
+
+
+def _cli(args):
+    return subprocess.run([CLI] + args, capture_output=True)
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="host/apm_parallel not built")
+def test_cli_matches_reference_stdout():
+    """scripts/basic_test.batch:10-18 / README.md:54-92: same banner and result lines."""
+    c = next(c for c in CASES if c["name"] == "cfg1_basic_test")
+    for extra in ([], ["DB_OVER_RANKS"], ["PATTERNS_OVER_RANKS"], ["--gpus", "1"], ["--kernel", "wavefront"]):
+        r = _cli(["0", c["path"]] + [p.decode() for p in c["patterns"]] + extra)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.decode().splitlines()
+        assert lines[0] == ("Approximate Pattern Mathing: looking for 6 pattern(s) in file %s w/ distance of 0" % c["path"])
+        assert lines[1].startswith("APM done in ") and lines[1].endswith(" s")
+        want = ["Number of matches for pattern <%s>: %d" % (p.decode(), n) for p, n in zip(c["patterns"], c["counts"])]
+        assert lines[2:] == want
+    c = next(c for c in CASES if c["name"] == "x100_k3")
+    r = _cli([str(c["k"]), c["path"]] + [p.decode() for p in c["patterns"]])
+    got = [int(l.rsplit(": ", 1)[1]) for l in r.stdout.decode().splitlines() if l.startswith("Number of matches")]
+    assert got == c["counts"]
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="host/apm_parallel not built")
+def test_cli_error_paths_match_reference():
+    errs = H.golden()["cli_errors"]
+    dna = os.path.join(H.GOLDEN_DIR, "dna")
+    for e in errs:
+        args = [a.replace("<dna>", dna) for a in e["args"]]
+        r = _cli(args)
+        assert r.returncode == e["rc"]
+        assert r.stderr.decode("latin-1") == e["stderr"]
+        assert r.stdout.decode("latin-1").replace(CLI, "<exe>").replace(dna, "<dna>") == e["stdout"]
