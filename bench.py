@@ -177,10 +177,9 @@ def main():
     shard_bytes = tm["text_bytes"]
     n_launch = tm["n_launches"]
 
-    expected = [1 if d == 0 else None for (_, d) in planted] if (k == 0 and args.config == "cfg2") else None
     counts_ok = all(c >= (1 if d <= k else 0) for c, (_, d) in zip(final_counts, planted))
-    if expected is not None:
-        counts_ok = counts_ok and all(c == (1 if d == 0 else 0) for c, (_, d) in zip(final_counts, planted))
+    if k == 0 and min(lens) >= 24:
+        counts_ok = counts_ok and final_counts == wl.expected_counts_k0(n_total, pats, planted, seed)
 
     if rank != 0:
         if world > 1:

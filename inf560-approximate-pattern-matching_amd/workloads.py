@@ -60,3 +60,20 @@ def algorithmic_cells(n, lens, k):
     tail windows are counted at m^2 too -- relative error < 1e-6 at these sizes)."""
     pos = max(0, n - k)
     return float(pos) * float(sum(m * m for m in lens))
+
+
+def expected_counts_k0(n, pats, planted, seed):
+    """Exact expected counts for k = 0 on the synthetic text, valid while no pattern recurs by
+    chance (m >= 24 on <= 2^40 bytes): the planted copy (if unmutated) plus the reference's
+    truncated tail windows (sequential.c:131-134): a window of size s < m at the very end of the
+    text matches when the last s text bytes equal the pattern's first s bytes."""
+    m_max = max(len(p) for p in pats)
+    tail = synth_fill_host(max(0, n - m_max), min(n, m_max), seed)
+    out = []
+    for p, (o, d) in zip(pats, planted):
+        c = 1 if d == 0 else 0
+        for s in range(1, min(len(p), n + 1)):
+            if s < len(p) and tail[len(tail) - s:] == p[:s]:
+                c += 1
+        out.append(c)
+    return out
