@@ -13,6 +13,9 @@
 #define APM_BITPAR_MAX_M 128
 #define APM_WAVEFRONT_MAX_M 256
 #define APM_LDS_TABLE_BUDGET (40 * 1024)
+#define APM_BANDED_MAX_M 256
+#define APM_BANDED_MAX_K 7
+#define APM_BANDED_MAX_PATS 64
 
 /* One pattern as a scan kernel sees it. */
 struct ApmPatDesc {
@@ -59,7 +62,48 @@ struct ApmGenericArgs {
     unsigned long long *counts;
 };
 
+/* BANDED (filter + verify) launch.  A key is the first 8 (or 4) bytes of one of the k+1
+ * disjoint pieces of a pattern; `off` is the piece's offset inside the pattern. */
+struct ApmKey {
+    uint32_t fp;        /* fingerprint of the key bytes (apm_fp8 / raw dword for 4-byte keys) */
+    uint16_t pat;       /* pattern slot inside the launch */
+    uint16_t off;       /* a_q: offset of the key inside the pattern */
+};
+
+#define APM_FILTER_POS 4096   /* text positions fingerprinted per workgroup (16 per lane) */
+
+struct ApmFilterArgs {
+    const uint8_t *text;
+    int64_t avail;
+    int64_t jb, je;
+    int64_t nrel;
+    int64_t tile0;         /* first window start of tile 0; text+tile0-front is 16-byte aligned */
+    const ApmPatDesc *pats;/* m, byte_off (into bytes), index */
+    const uint8_t *bytes;  /* raw pattern bytes of this launch */
+    const ApmKey *keys8;   /* 8-byte keys */
+    const ApmKey *keys4;   /* 4-byte keys */
+    unsigned long long *counts;
+    int n_pats, n8, n4;
+    int k, band;           /* band = k/2 */
+    int tile_w;            /* window starts per workgroup (multiple of 32) */
+    int front;             /* bytes staged in front of the first window (0 or 16) */
+    int tile_len;          /* bytes staged per workgroup (multiple of 16) */
+    int bytes_len;
+};
+
+struct ApmTailArgs {       /* truncated tail windows of patterns with m <= 128 */
+    const uint8_t *text;
+    int64_t jb, je, nrel;
+    const ApmPatDesc *pats;
+    const uint8_t *bytes;
+    unsigned long long *counts;
+    int k;
+};
+
 /* launchers (apm_kernels.hip) */
+hipError_t apm_launch_filter(const ApmFilterArgs &a, hipStream_t s);
+hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s);
+size_t apm_filter_lds_bytes(const ApmFilterArgs &a);
 hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s);

@@ -382,3 +382,220 @@ hipError_t apm_launch_synth(uint8_t *dst, uint64_t global_off, uint64_t len, uin
     hipLaunchKernelGGL(apm_synth_kernel, dim3((unsigned)nb), dim3(APM_BLOCK), 0, s, dst, global_off, len, seed);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// BANDED: exact shortcut for the predicate dist <= k.
+//
+// (1) Equal-length global alignment with <= k edits has #ins == #del <= k/2, so
+//     only the diagonals |x-y| <= band = k/2 can carry it (k<=1: Hamming).
+// (2) Pigeonhole: cut the pattern into k+1 disjoint pieces; <= k edits leave one
+//     piece intact, and it sits in the window at its own offset shifted by
+//     delta in [-band, band].  So a window is a CANDIDATE only if the first 8
+//     (4) bytes of some piece occur at text position j + off + delta.
+// Filter: every lane fingerprints 16 consecutive text positions held in LDS and
+// compares them with all keys of the launch (1.5 VALU ops per position x key:
+// v_xor, v_xor, v_min3); a hit marks its <= 2*band+1 candidate windows in an LDS
+// bitmap (dedup).  Verify: banded DP with early exit on the marked windows only.
+// Per launch the text is read from HBM exactly once (+ halo).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t apm_fp8(uint32_t lo, uint32_t hi) {
+    return lo ^ __builtin_amdgcn_alignbit(hi, hi, 29); // lo ^ rotl(hi, 3): injective on ACGT 8-mers
+}
+
+template <int BAND>
+__device__ __forceinline__ bool apm_banded_verify(const uint8_t *t, const uint8_t *p, int m, int k) {
+    if constexpr (BAND == 0) {
+        int mism = 0;
+        for (int x = 0; x < m; ++x) {
+            mism += (t[x] != p[x]) ? 1 : 0;
+            if (mism > k) return false;
+        }
+        return true;
+    } else {
+        constexpr int NB = 2 * BAND + 1;
+        constexpr int INF = 1 << 20;
+        int e[NB]; // e[d+BAND] = cell(x, x+d)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) e[i] = (i >= BAND) ? (i - BAND) : INF; // cell(0, d) = d
+        for (int x = 1; x <= m; ++x) {
+            const int tc = (int)t[x - 1];
+            int up = INF; // cell(x, y-1) of the previous diagonal at this x
+            int best = INF;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int y = x + i - BAND;
+                int nv;
+                if (y < 1) {
+                    nv = (y == 0) ? x : INF;
+                } else if (y > m) {
+                    nv = INF;
+                } else {
+                    const int diag = e[i] + (((int)p[y - 1] != tc) ? 1 : 0);
+                    const int left = (i + 1 < NB) ? e[i + 1] + 1 : INF;
+                    nv = apm_min3(diag, left, up + 1);
+                }
+                e[i] = nv;
+                up = nv;
+                best = min(best, nv);
+            }
+            if (best > k) return false;
+        }
+        return e[BAND] <= k;
+    }
+}
+
+template <int BAND>
+__global__ __launch_bounds__(APM_BLOCK) void apm_filter_kernel(ApmFilterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x;
+    constexpr int WORDS = APM_FILTER_POS / 32; // bitmap words per pattern
+    uint8_t *s_tile = smem;
+    uint8_t *s_pat = s_tile + a.tile_len;
+    uint32_t *s_map = reinterpret_cast<uint32_t *>(s_pat + ((a.bytes_len + 15) & ~15));
+    uint32_t *s_cnt = s_map + a.n_pats * WORDS;
+    const int64_t base = a.tile0 + (int64_t)blockIdx.x * a.tile_w; // first window start of the tile
+
+    for (int i = tid * 16; i < a.tile_len; i += APM_BLOCK * 16)
+        *reinterpret_cast<uint4 *>(s_tile + i) = apm_load16_guarded(a.text, base - a.front + i, a.avail);
+    for (int i = tid; i < a.bytes_len; i += APM_BLOCK) s_pat[i] = a.bytes[i];
+    for (int i = tid; i < a.n_pats * WORDS; i += APM_BLOCK) s_map[i] = 0u;
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
+    __syncthreads();
+
+    // ---- filter: 16 positions per lane ----
+    {
+        const int p0 = tid * 16; // LDS offset of this lane's first position
+        const uint4 va = *reinterpret_cast<const uint4 *>(s_tile + p0);
+        const uint2 vb = *reinterpret_cast<const uint2 *>(s_tile + p0 + 16);
+        const uint32_t w[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
+        uint32_t k0[20];
+#pragma unroll
+        for (int i = 0; i < 20; ++i)
+            k0[i] = (i & 3) ? __builtin_amdgcn_alignbyte(w[i / 4 + 1], w[i / 4], (uint32_t)(i & 3)) : w[i / 4];
+        uint32_t fp8[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fp8[i] = apm_fp8(k0[i], k0[i + 4]);
+
+        uint32_t acc = 0xffffffffu;
+        for (int q = 0; q + 1 < a.n8; q += 2) {
+            const uint32_t fa = a.keys8[q].fp, fb = a.keys8[q + 1].fp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = min(min(acc, fp8[i] ^ fa), fp8[i] ^ fb);
+        }
+        if (a.n8 & 1) {
+            const uint32_t fa = a.keys8[a.n8 - 1].fp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = min(acc, fp8[i] ^ fa);
+        }
+        for (int q = 0; q < a.n4; ++q) {
+            const uint32_t fa = a.keys4[q].fp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = min(acc, k0[i] ^ fa);
+        }
+
+        if (acc == 0u) { // rare: some (position, key) fingerprint matched -> mark candidate windows
+            auto mark = [&](const ApmKey key, int pos) {
+#pragma unroll
+                for (int dl = -BAND; dl <= BAND; ++dl) {
+                    const int jr = pos - a.front - (int)key.off - dl; // window start relative to base
+                    if (jr >= 0 && jr < a.tile_w) atomicOr(&s_map[(int)key.pat * WORDS + (jr >> 5)], 1u << (jr & 31));
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                for (int q = 0; q < a.n8; ++q)
+                    if (fp8[i] == a.keys8[q].fp) mark(a.keys8[q], p0 + i);
+                for (int q = 0; q < a.n4; ++q)
+                    if (k0[i] == a.keys4[q].fp) mark(a.keys4[q], p0 + i);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- verify the marked windows ----
+    for (int idx = tid; idx < a.n_pats * WORDS; idx += APM_BLOCK) {
+        uint32_t bits = s_map[idx];
+        if (!bits) continue;
+        const int pl = idx / WORDS, wd = idx - pl * WORDS;
+        const ApmPatDesc d = a.pats[pl];
+        const int m = (int)d.m;
+        const int64_t je_p = min(a.je, a.nrel - m + 1);
+        uint32_t hits = 0;
+        while (bits) {
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            const int jr = wd * 32 + b;
+            const int64_t j = base + jr;
+            if (j >= a.jb && j < je_p && apm_banded_verify<BAND>(s_tile + a.front + jr, s_pat + d.byte_off, m, a.k)) ++hits;
+        }
+        if (hits) atomicAdd(&s_cnt[pl], hits);
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
+        const uint32_t c = s_cnt[i];
+        if (c) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)c);
+    }
+}
+
+size_t apm_filter_lds_bytes(const ApmFilterArgs &a) {
+    return (size_t)a.tile_len + (size_t)((a.bytes_len + 15) & ~15) + (size_t)a.n_pats * (APM_FILTER_POS / 32) * 4 +
+           (size_t)a.n_pats * 4 + 16;
+}
+
+hipError_t apm_launch_filter(const ApmFilterArgs &a, hipStream_t s) {
+    const int64_t span = a.je - a.tile0;
+    if (span <= 0 || a.n_pats <= 0) return hipSuccess;
+    const int64_t nt = (span + a.tile_w - 1) / a.tile_w;
+    if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
+    const size_t lds = apm_filter_lds_bytes(a);
+    const dim3 g((unsigned)nt), b(APM_BLOCK);
+    switch (a.band) {
+    case 0: hipLaunchKernelGGL(apm_filter_kernel<0>, g, b, lds, s, a); break;
+    case 1: hipLaunchKernelGGL(apm_filter_kernel<1>, g, b, lds, s, a); break;
+    case 2: hipLaunchKernelGGL(apm_filter_kernel<2>, g, b, lds, s, a); break;
+    case 3: hipLaunchKernelGGL(apm_filter_kernel<3>, g, b, lds, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// TAIL: the <= m-1 truncated windows at the very end of the text
+// (sequential.c:131-134: window AND pattern cut to size = n - j), m <= 128.
+// One 128-lane workgroup per pattern; each lane runs the 4-word bit-vector
+// column for `size` steps over an Eq table built in LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void apm_tail_kernel(ApmTailArgs a) {
+    __shared__ uint4 s_eq[256];
+    const ApmPatDesc d = a.pats[blockIdx.x];
+    const int m = (int)d.m;
+    const uint8_t *pat = a.bytes + d.byte_off;
+    const int tid = threadIdx.x;
+    uint32_t *eqw = reinterpret_cast<uint32_t *>(s_eq);
+    for (int i = tid; i < 1024; i += 128) eqw[i] = 0u;
+    __syncthreads();
+    if (tid < m) atomicOr(&eqw[(int)pat[tid] * 4 + (tid >> 5)], 1u << (tid & 31));
+    __syncthreads();
+    const int64_t first_trunc = max(a.jb, a.nrel - m + 1);
+    const int64_t j = first_trunc + tid;
+    const bool valid = j < a.je;
+    const int size = valid ? (int)(a.nrel - j) : 0; // 1 .. m-1
+    uint32_t pv[4], mv[4];
+    bp_init<4>(pv, mv);
+    for (int x = 0; x < m - 1; ++x) {
+        if (x < size) {
+            const uint4 v = s_eq[a.text[j + x]];
+            const uint32_t eq[4] = {v.x, v.y, v.z, v.w};
+            bp_step<4>(pv, mv, eq);
+        }
+    }
+    const bool hit = valid && bp_distance<4>(pv, mv, size, size) <= a.k;
+    const uint32_t cnt = apm_wave_count(hit);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
+}
+
+hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s) {
+    if (n_pats <= 0 || a.je <= a.jb) return hipSuccess;
+    hipLaunchKernelGGL(apm_tail_kernel, dim3((unsigned)n_pats), dim3(128), 0, s, a);
+    return hipGetLastError();
+}

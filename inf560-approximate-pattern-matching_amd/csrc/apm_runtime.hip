@@ -57,6 +57,8 @@ struct TiledLaunch {       // host description of one tiled scan launch
     std::vector<uint8_t> bytes;
     std::vector<uint32_t> tables;
     uint8_t lut[256];
+    std::vector<ApmKey> keys8, keys4; // BANDED
+    int a_max = 0;                    // BANDED: largest key offset
     int m_max = 0, m_min = 0, tile = 0;
     double cells_per_pos = 0; // sum m^2 over its patterns
 };
@@ -71,6 +73,8 @@ struct DevTiled {
     uint8_t *d_bytes = nullptr;
     uint32_t *d_tables = nullptr;
     uint8_t *d_lut = nullptr;
+    ApmKey *d_keys8 = nullptr;
+    ApmKey *d_keys4 = nullptr;
 };
 
 struct DeviceState {
@@ -78,7 +82,8 @@ struct DeviceState {
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     uint8_t *d_allpat = nullptr;              // every pattern's raw bytes, concatenated
-    ApmPatDesc *d_tail_descs = nullptr;       // all non-trivial patterns (tails)
+    ApmPatDesc *d_tail_descs = nullptr;       // tails of tiled-kernel patterns with m > 128 (generic kernel)
+    ApmPatDesc *d_stail_descs = nullptr;      // tails of tiled-kernel patterns with m <= 128 (tail kernel)
     ApmPatDesc *d_long_descs = nullptr;       // generic full-scan patterns
     std::vector<DevTiled> tiled;
     unsigned long long *d_counts = nullptr;   // P
@@ -110,7 +115,8 @@ struct apm_ctx {
     std::vector<DeviceState> devs;
     std::vector<PatternInfo> pats;
     std::vector<TiledLaunch> tiled;
-    GenericGroup tails;   // every non-trivial pattern
+    GenericGroup tails;   // tiled-kernel patterns with m > 128: tails by the generic kernel
+    GenericGroup stails;  // tiled-kernel patterns with m <= 128: tails by the bit-vector tail kernel
     GenericGroup longs;   // patterns scanned fully by the generic kernel
     std::vector<int> trivial; // indices with k >= m
     std::vector<uint8_t> allpat;
@@ -165,6 +171,7 @@ int wavefront_rows_per_lane(int m) {
 int resolve_kernel(int forced, int m, int k, std::string *why) {
     if (forced == APM_KERNEL_AUTO) {
         if (k >= m) return KERNEL_TRIVIAL;
+        if (m <= APM_BANDED_MAX_M && k <= APM_BANDED_MAX_K && m / (k + 1) >= 4) return APM_KERNEL_BANDED;
         if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR;
         return APM_KERNEL_GENERIC;
     }
@@ -177,8 +184,11 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
         if (m > APM_BITPAR_MAX_M) { *why = "BITPAR kernel supports pattern length <= 128"; return -100; }
         return APM_KERNEL_BITPAR;
     case APM_KERNEL_BANDED:
-        *why = "BANDED kernel not built into this library version";
-        return -100;
+        if (m > APM_BANDED_MAX_M || k > APM_BANDED_MAX_K || m / (k + 1) < 4) {
+            *why = "BANDED kernel needs m <= 256, k <= 7 and m/(k+1) >= 4 (pigeonhole keys of >= 4 bytes)";
+            return -100;
+        }
+        return APM_KERNEL_BANDED;
     default: *why = "unknown kernel variant"; return -100;
     }
 }
@@ -190,10 +200,13 @@ void free_device_plan(DeviceState &ds) {
         if (t.d_bytes) hipFree(t.d_bytes);
         if (t.d_tables) hipFree(t.d_tables);
         if (t.d_lut) hipFree(t.d_lut);
+        if (t.d_keys8) hipFree(t.d_keys8);
+        if (t.d_keys4) hipFree(t.d_keys4);
     }
     ds.tiled.clear();
     if (ds.d_allpat) hipFree(ds.d_allpat), ds.d_allpat = nullptr;
     if (ds.d_tail_descs) hipFree(ds.d_tail_descs), ds.d_tail_descs = nullptr;
+    if (ds.d_stail_descs) hipFree(ds.d_stail_descs), ds.d_stail_descs = nullptr;
     if (ds.d_long_descs) hipFree(ds.d_long_descs), ds.d_long_descs = nullptr;
     if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
 }
@@ -210,6 +223,7 @@ int upload_vec(apm_ctx *ctx, T **dptr, const std::vector<T> &v) {
 int build_plan(apm_ctx *ctx) {
     ctx->tiled.clear();
     ctx->tails = GenericGroup();
+    ctx->stails = GenericGroup();
     ctx->longs = GenericGroup();
     ctx->trivial.clear();
     ctx->allpat.clear();
@@ -230,8 +244,9 @@ int build_plan(apm_ctx *ctx) {
         d.byte_off = raw_off[i];
         d.index = (uint32_t)i;
         if (kv != APM_KERNEL_GENERIC) { // GENERIC scans truncated windows itself (mode 2)
-            ctx->tails.descs.push_back(d);
-            ctx->tails.m_max = std::max(ctx->tails.m_max, ctx->pats[i].m);
+            GenericGroup &tg = ctx->pats[i].m <= 128 ? ctx->stails : ctx->tails;
+            tg.descs.push_back(d);
+            tg.m_max = std::max(tg.m_max, ctx->pats[i].m);
         } else {
             ctx->longs.descs.push_back(d);
             ctx->longs.m_max = std::max(ctx->longs.m_max, ctx->pats[i].m);
@@ -325,6 +340,52 @@ int build_plan(apm_ctx *ctx) {
         }
     }
 
+    // ---- BANDED launches: up to 64 patterns; k+1 pigeonhole keys per pattern ----
+    {
+        std::vector<int> idx;
+        for (int i = 0; i < P; ++i) if (ctx->pats[i].kernel == APM_KERNEL_BANDED) idx.push_back(i);
+        for (size_t pos = 0; pos < idx.size();) {
+            TiledLaunch L;
+            L.kind = APM_KERNEL_BANDED;
+            memset(L.lut, 0, sizeof L.lut);
+            for (; pos < idx.size() && L.descs.size() < APM_BANDED_MAX_PATS; ++pos) {
+                const PatternInfo &pi = ctx->pats[idx[pos]];
+                ApmPatDesc d{};
+                d.m = (uint32_t)pi.m;
+                d.index = (uint32_t)idx[pos];
+                d.byte_off = (uint32_t)L.bytes.size();
+                L.bytes.insert(L.bytes.end(), pi.bytes.begin(), pi.bytes.end());
+                const int pieces = ctx->k + 1;
+                const int lk = (pi.m / pieces >= 8) ? 8 : 4;
+                for (int q = 0; q < pieces; ++q) {
+                    const int aq = (int)((int64_t)q * pi.m / pieces);
+                    const unsigned char *b = (const unsigned char *)pi.bytes.data() + aq;
+                    const uint32_t lo = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
+                    ApmKey key{};
+                    key.pat = (uint16_t)L.descs.size();
+                    key.off = (uint16_t)aq;
+                    if (lk == 8) {
+                        const uint32_t hi = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
+                        key.fp = lo ^ ((hi << 3) | (hi >> 29));
+                        L.keys8.push_back(key);
+                    } else {
+                        key.fp = lo;
+                        L.keys4.push_back(key);
+                    }
+                    L.a_max = std::max(L.a_max, aq);
+                }
+                L.descs.push_back(d);
+                L.m_max = std::max(L.m_max, pi.m);
+                L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
+                L.cells_per_pos += double(pi.m) * (2 * (ctx->k / 2) + 1);
+            }
+            const int band = ctx->k / 2;
+            const int front = band > 0 ? 16 : 0;
+            L.tile = (APM_FILTER_POS - front - L.a_max - band) & ~31;
+            ctx->tiled.push_back(std::move(L));
+        }
+    }
+
     // ---- upload to every device ----
     for (auto &ds : ctx->devs) {
         free_device_plan(ds);
@@ -332,6 +393,7 @@ int build_plan(apm_ctx *ctx) {
         int rc;
         if ((rc = upload_vec(ctx, &ds.d_allpat, ctx->allpat))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_tail_descs, ctx->tails.descs))) return rc;
+        if ((rc = upload_vec(ctx, &ds.d_stail_descs, ctx->stails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_long_descs, ctx->longs.descs))) return rc;
         HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
         ds.tiled.resize(ctx->tiled.size());
@@ -342,6 +404,8 @@ int build_plan(apm_ctx *ctx) {
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_tables, L.tables))) return rc;
             std::vector<uint8_t> lut(L.lut, L.lut + 256);
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_lut, lut))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_keys8, L.keys8))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_keys4, L.keys4))) return rc;
         }
     }
     return APM_OK;
@@ -416,6 +480,32 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         const TiledLaunch &L = ctx->tiled[t];
         const int64_t je_l = std::min<int64_t>(je, nrel - L.m_min + 1);
         if (je_l <= jb) continue;
+        if (L.kind == APM_KERNEL_BANDED) {
+            ApmFilterArgs f{};
+            f.text = d_text;
+            f.avail = avail;
+            f.jb = jb;
+            f.je = je_l;
+            f.nrel = nrel;
+            f.band = ctx->k / 2;
+            f.front = f.band > 0 ? 16 : 0;
+            f.tile0 = jb - (int64_t)((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)jb - (uintptr_t)f.front) & 15u);
+            f.pats = ds.tiled[t].d_descs;
+            f.bytes = ds.tiled[t].d_bytes;
+            f.keys8 = ds.tiled[t].d_keys8;
+            f.keys4 = ds.tiled[t].d_keys4;
+            f.counts = d_counts;
+            f.n_pats = (int)L.descs.size();
+            f.n8 = (int)L.keys8.size();
+            f.n4 = (int)L.keys4.size();
+            f.k = ctx->k;
+            f.tile_w = L.tile;
+            f.tile_len = (std::max(APM_FILTER_POS + 24, f.front + L.tile + L.m_max) + 15) & ~15;
+            f.bytes_len = (int)L.bytes.size();
+            HIP_TRY(ctx, apm_launch_filter(f, ds.stream));
+            ds.launches++;
+            continue;
+        }
         ApmScanArgs a{};
         a.text = d_text;
         a.avail = avail;
@@ -442,9 +532,22 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
     // truncated tail windows (only the shard owning the end of the text has any)
-    if (nrel - (int64_t)ctx->tails.m_max + 1 < je) {
+    if (!ctx->tails.descs.empty() && nrel - (int64_t)ctx->tails.m_max + 1 < je) {
         rc = launch_generic_group(ctx, ds, ctx->tails, ds.d_tail_descs, 1, d_text, avail, jb, je, nrel, d_counts);
         if (rc) return rc;
+    }
+    if (!ctx->stails.descs.empty() && nrel - (int64_t)ctx->stails.m_max + 1 < je) {
+        ApmTailArgs ta{};
+        ta.text = d_text;
+        ta.jb = jb;
+        ta.je = je;
+        ta.nrel = nrel;
+        ta.pats = ds.d_stail_descs;
+        ta.bytes = ds.d_allpat;
+        ta.counts = d_counts;
+        ta.k = ctx->k;
+        HIP_TRY(ctx, apm_launch_tail(ta, (int)ctx->stails.descs.size(), ds.stream));
+        ds.launches++;
     }
     for (int i : ctx->trivial)
         hipLaunchKernelGGL(apm_add_const_kernel, dim3(1), dim3(64), 0, ds.stream, d_counts, i,
@@ -470,7 +573,10 @@ void account(apm_ctx *ctx, uint64_t n_total, uint64_t ob, uint64_t oe) {
         }
         ctx->timing.windows += oe - ob;
         ctx->timing.cells_algorithmic += cells;
-        if (p.kernel != KERNEL_TRIVIAL) ctx->timing.cells_evaluated += cells;
+        if (p.kernel == APM_KERNEL_BANDED)
+            ctx->timing.cells_evaluated += double(oe - ob) * double(m) * double(2 * (ctx->k / 2) + 1); // upper bound
+        else if (p.kernel != KERNEL_TRIVIAL)
+            ctx->timing.cells_evaluated += cells;
     }
 }
 

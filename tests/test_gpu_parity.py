@@ -13,8 +13,18 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["auto", "bitpar", "wavefront", "generic"]
-MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 128, "wavefront": 256}
+VARIANTS = ["auto", "banded", "bitpar", "wavefront", "generic"]
+MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 128, "wavefront": 256, "banded": 256}
+
+
+def _supported(variant, m, k):
+    """mirror of the library's documented limits (include/apm.h, apm_set_kernel -> UNSUPPORTED)"""
+    if m > MAX_M[variant]:
+        return False
+    if variant == "banded":
+        return k <= 7 and m // (k + 1) >= 4
+    return True
+
 CASES = H.golden()["cases"]
 
 
@@ -43,7 +53,7 @@ def _run(ctx, apm, variant, patterns, k, text):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_golden(ctx, apm, case, variant):
     pats, k = case["patterns"], case["k"]
-    if max(len(p) for p in pats) > MAX_M[variant]:
+    if not all(_supported(variant, len(p), k) for p in pats):
         ctx.set_kernel("auto")
         ctx.set_patterns(pats, k)
         with pytest.raises(apm.ApmError) as e:      # error behaviour: UNSUPPORTED, state unchanged
@@ -98,19 +108,22 @@ def test_random_vs_oracle(ctx, apm, variant):
                 p = bytes(rnd.choice(alpha) for _ in range(m))
             pats.append(p)
         k = rnd.choice([0, 0, 1, 2, 3, 4, 5, 6, 9])
+        pats = [p for p in pats if _supported(variant, len(p), k)]
+        if not pats:
+            continue
         want = H.oracle_counts(text, pats, k)
         got = _run(ctx, apm, variant, pats, k, text)
         assert got == want, (trial, n, k, [len(p) for p in pats])
 
 
-@pytest.mark.parametrize("variant", ["auto", "bitpar", "wavefront"])
+@pytest.mark.parametrize("variant", ["auto", "banded", "bitpar", "wavefront"])
 def test_tile_boundaries(ctx, apm, variant):
     """a planted occurrence straddling every tile seam is found exactly once"""
     rnd = random.Random(99)
-    n = 5000
+    n = 9000
     base = bytearray(rnd.choice(b"ACGT") for _ in range(n))
     pat = bytes(rnd.choice(b"ACGT") for _ in range(40))
-    for seam in (512, 1024, 2048, 3072, 4096):
+    for seam in (512, 1024, 2048, 3072, 4000, 4040, 4064, 4080, 4096):
         for off in (-39, -20, -1, 0, 1):
             text = bytearray(base)
             o = seam + off
@@ -134,6 +147,8 @@ def test_duplicate_and_many_patterns(ctx, apm):
     pats[17] = pats[3]
     want = H.oracle_counts(text, pats, 1, banded=True)
     assert _run(ctx, apm, "auto", pats, 1, text) == want
+    assert _run(ctx, apm, "banded", pats, 1, text) == want
+    assert _run(ctx, apm, "bitpar", pats, 1, text) == want
     assert _run(ctx, apm, "wavefront", pats, 1, text) == want
 
 
@@ -173,7 +188,7 @@ def test_sharded_equals_unsharded(ctx, n_shards):
     for name in ("chrY_k3", "x100_k2", "dna20k_k5"):
         c = next(c for c in CASES if c["name"] == name)
         text = H.case_text(c)
-        for variant in ("auto", "wavefront"):
+        for variant in ("auto", "wavefront", "bitpar"):
             ctx.set_kernel("auto")
             ctx.set_patterns(c["patterns"], c["k"])
             ctx.set_kernel(variant)
@@ -234,7 +249,7 @@ def test_baseline_workloads_small_vs_oracle(ctx, apm, cfg):
     want = H.oracle_counts(text, pats, c["k"], banded=True)
     for (o, d), w in zip(planted, want):
         assert (w >= 1) or d > c["k"]
-    for variant in ("auto", "bitpar", "wavefront"):
+    for variant in ("auto", "banded", "bitpar", "wavefront"):
         ctx.set_kernel("auto")
         ctx.set_patterns(pats, c["k"])
         ctx.set_kernel(variant)
@@ -324,3 +339,42 @@ def test_cli_error_paths_match_reference():
         assert r.returncode == e["rc"]
         assert r.stderr.decode("latin-1") == e["stderr"]
         assert r.stdout.decode("latin-1").replace(CLI, "<exe>").replace(dna, "<dna>") == e["stdout"]
+
+
+# ---------------------------------------------------------------- adversarial inputs for the filter
+@pytest.mark.parametrize("variant", ["auto", "banded", "bitpar"])
+def test_low_entropy_text_every_window_is_a_candidate(ctx, apm, variant):
+    """runs of one letter / short periods: every position hits the q-gram filter, every window is
+    verified; counts must still equal the oracle (rule 26: force the rare branch)."""
+    texts = [b"A" * 9000, b"AC" * 4500, (b"ACGT" * 8 + b"T") * 280, b"A" * 4095 + b"C" + b"A" * 4904]
+    for text in texts:
+        for k in (0, 1, 2, 3, 5):
+            pats = [text[100:100 + m] for m in (24, 32, 50, 64, 128)] + [b"A" * 31 + b"C", b"C" + b"A" * 40]
+            pats = [p for p in pats if _supported(variant, len(p), k)]
+            want = H.oracle_counts(text, pats, k, banded=True)
+            assert _run(ctx, apm, variant, pats, k, text) == want, (len(text), k)
+
+
+def test_custom_unaligned_shard_cuts(ctx, apm):
+    """own ranges cut at arbitrary (non 16-byte) positions add up to the whole"""
+    c = next(c for c in CASES if c["name"] == "x100_k2")
+    text, pats, k = H.case_text(c), c["patterns"], c["k"]
+    n = len(text)
+    m_max = max(len(p) for p in pats)
+    for variant in ("auto", "bitpar", "wavefront"):
+        ctx.set_kernel("auto")
+        ctx.set_patterns(pats, k)
+        ctx.set_kernel(variant)
+        d_counts = ctx.device_alloc(8 * len(pats))
+        ctx.device_memset(d_counts, 0, 8 * len(pats))
+        cuts = [0, 7, 1001, 4099, 65537, 100003, n]
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            lo, hi = max(0, b - 3), min(n, e + m_max - 1)
+            d_text = ctx.device_alloc(hi - lo + 16)
+            ctx.device_upload(d_text, text[lo:hi])
+            ctx.count_shard_device(d_text, lo, hi - lo, n, b, e, d_counts)
+            ctx.synchronize()
+            ctx.device_free(d_text)
+        raw = ctx.device_download(d_counts, 8 * len(pats))
+        ctx.device_free(d_counts)
+        assert [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(len(pats))] == c["counts"], variant
