@@ -14,6 +14,7 @@
 #define APM_WAVEFRONT_MAX_M 256
 #define APM_LDS_TABLE_BUDGET (40 * 1024)
 #define APM_BANDED_MAX_M 256
+#define APM_BANDED_MIN_PIECE 8
 #define APM_BANDED_MAX_K 7
 #define APM_BANDED_MAX_PATS 64
 
@@ -62,34 +63,47 @@ struct ApmGenericArgs {
     unsigned long long *counts;
 };
 
-/* BANDED (filter + verify) launch.  A key is the first 8 (or 4) bytes of one of the k+1
- * disjoint pieces of a pattern; `off` is the piece's offset inside the pattern. */
+/* BANDED (filter + verify) launch.  A key is a KL-byte sub-block of one of the k+1 disjoint
+ * pieces of a pattern; `off` is its offset inside the pattern (piece offset + r). */
 struct ApmKey {
-    uint32_t fp;        /* fingerprint of the key bytes (apm_fp8 / raw dword for 4-byte keys) */
+    uint32_t fp;        /* fingerprint of the KL key bytes (apm_fp8 / apm_fp16) */
     uint16_t pat;       /* pattern slot inside the launch */
-    uint16_t off;       /* a_q: offset of the key inside the pattern */
+    uint16_t off;       /* offset of the key bytes inside the pattern */
+    uint16_t piece;     /* index q of the piece it belongs to */
+    uint16_t next;      /* 1 + id of the next key with the same fingerprint (0 = end of chain) */
 };
 
-#define APM_FILTER_POS 4096   /* text positions fingerprinted per workgroup (16 per lane) */
+#define APM_FILTER_POS 4096   /* text bytes fingerprinted per workgroup tile (16 per lane) */
 
 struct ApmFilterArgs {
     const uint8_t *text;
     int64_t avail;
+    int64_t avail_pad;     /* avail rounded up so that text+avail_pad is 16-byte aligned (same allocation granule) */
     int64_t jb, je;
     int64_t nrel;
     int64_t tile0;         /* first window start of tile 0; text+tile0-front is 16-byte aligned */
-    const ApmPatDesc *pats;/* m, byte_off (into bytes), index */
-    const uint8_t *bytes;  /* raw pattern bytes of this launch */
-    const ApmKey *keys8;   /* 8-byte keys */
-    const ApmKey *keys4;   /* 4-byte keys */
+    int64_t ntiles;
+    const ApmPatDesc *pats;/* m, byte_off (into bytes), index, aux_off = first entry in piece_off, w = pieces (k+1) */
+    const uint8_t *bytes;  /* raw pattern bytes of this launch (padded to 16) */
+    const ApmKey *keys;    /* nk sub-keys */
+    const uint16_t *piece_off; /* piece offsets a_q, per pattern contiguous */
+    const uint4 *table;    /* nb buckets x 4 fingerprint tags (empty = APM_TAG_EMPTY) */
+    const uint16_t *table_kid; /* nb x 4 key ids */
+    const uint32_t *ovf;   /* n_ovf x {fp, kid}: keys whose bucket was full */
     unsigned long long *counts;
-    int n_pats, n8, n4;
+    int n_pats, nk;
+    int nb, lg_nb, n_ovf;  /* hash table geometry */
+    int qcap;              /* candidate queue entries */
+    int key_len, stride;   /* (16,16), (8,8) or (8,1) */
     int k, band;           /* band = k/2 */
-    int tile_w;            /* window starts per workgroup (multiple of 32) */
+    int tile_w;            /* window starts per workgroup tile (multiple of 32) */
     int front;             /* bytes staged in front of the first window (0 or 16) */
-    int tile_len;          /* bytes staged per workgroup (multiple of 16) */
+    int tile_len;          /* bytes staged per tile (multiple of 16) */
     int bytes_len;
+    int ablate;            /* measurement aid (APM_FILTER_ABLATE); 0 in production */
 };
+
+#define APM_TAG_EMPTY 0x5bd1e995u
 
 struct ApmTailArgs {       /* truncated tail windows of patterns with m <= 128 */
     const uint8_t *text;
@@ -101,9 +115,10 @@ struct ApmTailArgs {       /* truncated tail windows of patterns with m <= 128 *
 };
 
 /* launchers (apm_kernels.hip) */
-hipError_t apm_launch_filter(const ApmFilterArgs &a, hipStream_t s);
+hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t s);
 hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s);
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a);
+int apm_filter_blocks_per_cu(int band, int key_len, int stride, size_t lds);
 hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s);

@@ -390,16 +390,47 @@ hipError_t apm_launch_synth(uint8_t *dst, uint64_t global_off, uint64_t len, uin
 //     only the diagonals |x-y| <= band = k/2 can carry it (k<=1: Hamming).
 // (2) Pigeonhole: cut the pattern into k+1 disjoint pieces; <= k edits leave one
 //     piece intact, and it sits in the window at its own offset shifted by
-//     delta in [-band, band].  So a window is a CANDIDATE only if the first 8
-//     (4) bytes of some piece occur at text position j + off + delta.
-// Filter: every lane fingerprints 16 consecutive text positions held in LDS and
-// compares them with all keys of the launch (1.5 VALU ops per position x key:
-// v_xor, v_xor, v_min3); a hit marks its <= 2*band+1 candidate windows in an LDS
-// bitmap (dedup).  Verify: banded DP with early exit on the marked windows only.
-// Per launch the text is read from HBM exactly once (+ halo).
+//     delta in [-band, band].
+// (3) Sampling: a piece of length L >= 2*KL-1 contains a KL-byte block that is
+//     KL-ALIGNED in the text whatever the window's alignment; so it is enough to
+//     look at every KL-th text position (STRIDE = KL) and to know, per piece,
+//     its KL shifted sub-keys pattern[a_q + r : a_q + r + KL), r = 0..KL-1.
+//     Shorter pieces (L >= KL) use STRIDE = 1 (every position, r = 0).
+// A window is a CANDIDATE only if some sub-key occurs at a sampled text position
+// consistent with it:  j = position - (a_q + r) - delta.
+//
+// Workgroup = persistent, software-pipelined walker over tiles of 4096 text
+// bytes (16 per lane): the 16-byte buffer loads of tiles t+G and t+2G are in
+// flight while tile t is processed out of LDS.  Per tile:
+//   filter   each lane fingerprints its 16/STRIDE sampled positions and looks the
+//            fingerprint up in an LDS hash table of all sub-keys of the launch
+//            (4-way buckets of 32-bit tags + a short overflow list): ~10 VALU
+//            ops and one ds_read_b128 per lookup, independent of the key count;
+//   enqueue  a tag match pushes (key, position) into an LDS queue;
+//   verify   all lanes pop the queue: byte-compare the key (fingerprints can
+//            collide), banded DP with early exit over the candidate window,
+//            and count it only from its FIRST true (piece, shift) nominator so a
+//            window nominated several times is counted once (stateless dedup).
+// A queue overflow (adversarial low-entropy text) falls back to a dense pass of
+// the same verification over every (sampled position, key) of the tile.
+// Per launch the text is read from HBM exactly once (+ halo per tile).
 // ---------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint32_t apm_fp8(uint32_t lo, uint32_t hi) {
-    return lo ^ __builtin_amdgcn_alignbit(hi, hi, 29); // lo ^ rotl(hi, 3): injective on ACGT 8-mers
+    return lo + (hi << 3); // v_lshl_add_u32; injective on ACGT 8-mers (no carries between bytes)
+}
+__device__ __forceinline__ uint32_t apm_fp16(uint32_t f_lo, uint32_t f_hi) {
+    return f_lo + __umul24(f_hi, 0x9E3779u); // v_mad_u32_u24: 16 text bytes -> 32 bits
+}
+__device__ __forceinline__ uint32_t apm_slot_hash(uint32_t f) {
+    return __umul24(f, 0x9E3779u) + (f >> 11); // bucket = top bits
+}
+
+__device__ __forceinline__ bool apm_bytes_equal(const uint8_t *x, const uint8_t *y, int n) {
+    for (int i = 0; i < n; ++i)
+        if (x[i] != y[i]) return false;
+    return true;
 }
 
 template <int BAND>
@@ -444,93 +475,177 @@ __device__ __forceinline__ bool apm_banded_verify(const uint8_t *t, const uint8_
     }
 }
 
-template <int BAND>
-__global__ __launch_bounds__(APM_BLOCK) void apm_filter_kernel(ApmFilterArgs a) {
+template <int BAND, int KL, int STRIDE>
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : 6) void apm_filter_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
-    constexpr int WORDS = APM_FILTER_POS / 32; // bitmap words per pattern
-    uint8_t *s_tile = smem;
-    uint8_t *s_pat = s_tile + a.tile_len;
-    uint32_t *s_map = reinterpret_cast<uint32_t *>(s_pat + ((a.bytes_len + 15) & ~15));
-    uint32_t *s_cnt = s_map + a.n_pats * WORDS;
-    const int64_t base = a.tile0 + (int64_t)blockIdx.x * a.tile_w; // first window start of the tile
+    uint8_t *s_tile0 = smem;
+    uint8_t *s_tile1 = smem + a.tile_len;
+    uint8_t *s_pat = s_tile1 + a.tile_len;
+    uint4 *s_tab = reinterpret_cast<uint4 *>(s_pat + ((a.bytes_len + 15) & ~15)); // nb buckets x 4 tags
+    uint16_t *s_kid = reinterpret_cast<uint16_t *>(s_tab + a.nb);                  // nb x 4 key ids
+    uint32_t *s_ovf = reinterpret_cast<uint32_t *>(s_kid + 4 * a.nb);              // n_ovf x {fp, kid}
+    uint32_t *s_queue = s_ovf + 2 * ((a.n_ovf + 1) & ~1);
+    uint32_t *s_cnt = s_queue + a.qcap;
+    uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [2]
 
-    for (int i = tid * 16; i < a.tile_len; i += APM_BLOCK * 16)
-        *reinterpret_cast<uint4 *>(s_tile + i) = apm_load16_guarded(a.text, base - a.front + i, a.avail);
-    for (int i = tid; i < a.bytes_len; i += APM_BLOCK) s_pat[i] = a.bytes[i];
-    for (int i = tid; i < a.n_pats * WORDS; i += APM_BLOCK) s_map[i] = 0u;
+    const int n16 = a.tile_len >> 4;
+    const bool second = tid + APM_BLOCK < n16;
+    // Branch-free tile fetch: raw buffer loads, the descriptor's num_records does the bounds
+    // check (out-of-range lanes return 0 and move no data), so the loads stay in flight across
+    // the processing of the previous tiles instead of being fenced by control flow.
+    auto fetch = [&](int64_t t, u32x4 &r0, u32x4 &r1) {
+        const int64_t g = a.tile0 + t * a.tile_w - a.front; // >= -31
+        const int64_t gb = g > 0 ? g : 0;
+        const int64_t lim = a.avail_pad - gb;
+        const uint32_t nrec = lim <= 0 ? 0u : (lim > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)lim);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + gb, 0, (int)nrec, 0x00020000);
+        const uint32_t o0 = (uint32_t)((int)(g - gb) + 16 * tid); // negative wraps -> out of range -> 0
+        const uint32_t o1 = second ? o0 + 16u * APM_BLOCK : 0xfffffff0u;
+        r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0, 0, 0);
+        r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o1, 0, 0);
+    };
+    auto stash = [&](uint8_t *buf, const u32x4 &r0, const u32x4 &r1) {
+        *reinterpret_cast<u32x4 *>(buf + 16 * tid) = r0;
+        if (second) *reinterpret_cast<u32x4 *>(buf + 16 * (tid + APM_BLOCK)) = r1;
+    };
+
+    const int64_t G = gridDim.x;
+    int64_t t = blockIdx.x;
+    u32x4 ra0 = {0, 0, 0, 0}, ra1 = {0, 0, 0, 0}, rb0 = {0, 0, 0, 0}, rb1 = {0, 0, 0, 0};
+    if (t < a.ntiles) fetch(t, ra0, ra1);
+    for (int i = tid * 4; i < a.bytes_len; i += APM_BLOCK * 4) // pool is padded to 16 bytes
+        *reinterpret_cast<uint32_t *>(s_pat + i) = *reinterpret_cast<const uint32_t *>(a.bytes + i);
+    for (int i = tid; i < a.nb; i += APM_BLOCK) s_tab[i] = a.table[i];
+    for (int i = tid; i < 2 * a.nb; i += APM_BLOCK)
+        reinterpret_cast<uint32_t *>(s_kid)[i] = reinterpret_cast<const uint32_t *>(a.table_kid)[i];
+    for (int i = tid; i < 2 * a.n_ovf; i += APM_BLOCK) s_ovf[i] = a.ovf[i];
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
-    __syncthreads();
-
-    // ---- filter: 16 positions per lane ----
-    {
-        const int p0 = tid * 16; // LDS offset of this lane's first position
-        const uint4 va = *reinterpret_cast<const uint4 *>(s_tile + p0);
-        const uint2 vb = *reinterpret_cast<const uint2 *>(s_tile + p0 + 16);
-        const uint32_t w[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
-        uint32_t k0[20];
-#pragma unroll
-        for (int i = 0; i < 20; ++i)
-            k0[i] = (i & 3) ? __builtin_amdgcn_alignbyte(w[i / 4 + 1], w[i / 4], (uint32_t)(i & 3)) : w[i / 4];
-        uint32_t fp8[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) fp8[i] = apm_fp8(k0[i], k0[i + 4]);
-
-        uint32_t acc = 0xffffffffu;
-        for (int q = 0; q + 1 < a.n8; q += 2) {
-            const uint32_t fa = a.keys8[q].fp, fb = a.keys8[q + 1].fp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc = min(min(acc, fp8[i] ^ fa), fp8[i] ^ fb);
-        }
-        if (a.n8 & 1) {
-            const uint32_t fa = a.keys8[a.n8 - 1].fp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc = min(acc, fp8[i] ^ fa);
-        }
-        for (int q = 0; q < a.n4; ++q) {
-            const uint32_t fa = a.keys4[q].fp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc = min(acc, k0[i] ^ fa);
-        }
-
-        if (acc == 0u) { // rare: some (position, key) fingerprint matched -> mark candidate windows
-            auto mark = [&](const ApmKey key, int pos) {
-#pragma unroll
-                for (int dl = -BAND; dl <= BAND; ++dl) {
-                    const int jr = pos - a.front - (int)key.off - dl; // window start relative to base
-                    if (jr >= 0 && jr < a.tile_w) atomicOr(&s_map[(int)key.pat * WORDS + (jr >> 5)], 1u << (jr & 31));
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                for (int q = 0; q < a.n8; ++q)
-                    if (fp8[i] == a.keys8[q].fp) mark(a.keys8[q], p0 + i);
-                for (int q = 0; q < a.n4; ++q)
-                    if (k0[i] == a.keys4[q].fp) mark(a.keys4[q], p0 + i);
-            }
-        }
+    if (tid < 2) s_qn[tid] = 0u;
+    if (t < a.ntiles) {
+        stash(s_tile0, ra0, ra1);
+        if (t + G < a.ntiles) fetch(t + G, ra0, ra1);         // A: tile t+G   -> lands in buffer 1
+        if (t + 2 * G < a.ntiles) fetch(t + 2 * G, rb0, rb1); // B: tile t+2G -> lands in buffer 0
     }
     __syncthreads();
 
-    // ---- verify the marked windows ----
-    for (int idx = tid; idx < a.n_pats * WORDS; idx += APM_BLOCK) {
-        uint32_t bits = s_map[idx];
-        if (!bits) continue;
-        const int pl = idx / WORDS, wd = idx - pl * WORDS;
-        const ApmPatDesc d = a.pats[pl];
+    // verification of one (key, sampled text position) nomination; bumps s_cnt
+    auto verify_entry = [&](const uint8_t *s_tile, int64_t base, int kid, int pos) {
+        const ApmKey key = a.keys[kid];
+        const ApmPatDesc d = a.pats[key.pat];
+        const uint8_t *pat = s_pat + d.byte_off;
+        if (!apm_bytes_equal(s_tile + pos, pat + key.off, KL)) return; // fingerprint collision
         const int m = (int)d.m;
         const int64_t je_p = min(a.je, a.nrel - m + 1);
-        uint32_t hits = 0;
-        while (bits) {
-            const int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            const int jr = wd * 32 + b;
+        for (int dl = -BAND; dl <= BAND; ++dl) {
+            const int jr = pos - a.front - (int)key.off - dl; // window start relative to base
             const int64_t j = base + jr;
-            if (j >= a.jb && j < je_p && apm_banded_verify<BAND>(s_tile + a.front + jr, s_pat + d.byte_off, m, a.k)) ++hits;
+            if (jr < 0 || jr >= a.tile_w || j < a.jb || j >= je_p) continue;
+            if (!apm_banded_verify<BAND>(s_tile + a.front + jr, pat, m, a.k)) continue;
+            // count the window once: only from its first true (piece, shift) nominator
+            bool first = true;
+            for (int qq = 0; qq <= (int)key.piece && first; ++qq) {
+                const int aq = (int)a.piece_off[d.aux_off + qq];
+                for (int dd = -BAND; dd <= BAND; ++dd) {
+                    if (qq == (int)key.piece && dd >= dl) break;
+                    const int o = a.front + jr + aq + dd;           // piece start under shift dd
+                    const int rr = (STRIDE - (o % STRIDE)) % STRIDE; // its sampled (aligned) block
+                    if (apm_bytes_equal(s_tile + o + rr, pat + aq + rr, KL)) {
+                        first = false;
+                        break;
+                    }
+                }
+            }
+            if (first) atomicAdd(&s_cnt[key.pat], 1u);
         }
-        if (hits) atomicAdd(&s_cnt[pl], hits);
+    };
+
+    const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
+
+    auto iteration = [&](int it, int64_t t, const uint8_t *s_tile, uint8_t *s_other, u32x4 &r0, u32x4 &r1) {
+        const int cur = it & 1;
+        const int64_t base = a.tile0 + t * a.tile_w; // first window start of the tile
+        const int p0 = tid * 16;                     // LDS offset of this lane's first position
+
+        // ---- fingerprints of this lane's sampled positions ----
+        constexpr int NF = 16 / STRIDE;
+        uint32_t f[NF];
+        {
+            const uint4 va = *reinterpret_cast<const uint4 *>(s_tile + p0);
+            if constexpr (STRIDE == 16) {
+                f[0] = apm_fp16(apm_fp8(va.x, va.y), apm_fp8(va.z, va.w));
+            } else if constexpr (STRIDE == 8) {
+                f[0] = apm_fp8(va.x, va.y);
+                f[1] = apm_fp8(va.z, va.w);
+            } else { // every position: KL = 8
+                const uint2 vb = *reinterpret_cast<const uint2 *>(s_tile + p0 + 16);
+                const uint32_t w[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
+                uint32_t k0[20];
+#pragma unroll
+                for (int i = 0; i < 20; ++i)
+                    k0[i] = (i & 3) ? __builtin_amdgcn_alignbyte(w[i / 4 + 1], w[i / 4], (uint32_t)(i & 3)) : w[i / 4];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) f[i] = apm_fp8(k0[i], k0[i + 4]);
+            }
+        }
+
+        // ---- filter + enqueue: one hash-table probe per sampled position ----
+        if (!(a.ablate & 1)) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const uint32_t fi = f[i];
+                const uint32_t slot = apm_slot_hash(fi) >> hshift;
+                const uint4 tg = s_tab[slot];
+                bool hit = (tg.x == fi) | (tg.y == fi) | (tg.z == fi) | (tg.w == fi);
+                for (int o = 0; o < a.n_ovf; ++o) hit |= (s_ovf[2 * o] == fi);
+                if (hit) { // rare with long keys
+                    auto push = [&](uint32_t kid) { // a table entry heads a chain of keys with equal fingerprint
+                        for (;;) {
+                            const uint32_t idx = atomicAdd(&s_qn[cur], 1u);
+                            if (idx < (uint32_t)a.qcap) s_queue[idx] = (kid << 16) | (uint32_t)(p0 + i * STRIDE);
+                            const uint32_t nxt = a.keys[kid].next;
+                            if (!nxt) break;
+                            kid = nxt - 1u;
+                        }
+                    };
+                    if (tg.x == fi) push(s_kid[4 * slot + 0]);
+                    if (tg.y == fi) push(s_kid[4 * slot + 1]);
+                    if (tg.z == fi) push(s_kid[4 * slot + 2]);
+                    if (tg.w == fi) push(s_kid[4 * slot + 3]);
+                    for (int o = 0; o < a.n_ovf; ++o)
+                        if (s_ovf[2 * o] == fi) push(s_ovf[2 * o + 1]);
+                }
+            }
+        }
+        __syncthreads(); // A: queue complete
+
+        // ---- verify ----
+        const uint32_t qn = s_qn[cur];
+        if (tid == 0) s_qn[cur ^ 1] = 0u; // next iteration's counter (nobody reads it before barrier B)
+        if (qn <= (uint32_t)a.qcap) {
+            for (uint32_t e = tid; e < qn; e += APM_BLOCK) {
+                const uint32_t ent = s_queue[e];
+                verify_entry(s_tile, base, (int)(ent >> 16), (int)(ent & 0xffffu));
+            }
+        } else { // queue overflow: dense pass over every (sampled position, key)
+            for (int i = 0; i < NF; ++i)
+                for (int kid = 0; kid < a.nk; ++kid) verify_entry(s_tile, base, kid, p0 + i * STRIDE);
+        }
+
+        // ---- land tile t+G in the other buffer, start fetching tile t+3G ----
+        if (t + G < a.ntiles) {
+            stash(s_other, r0, r1);
+            if (t + 3 * G < a.ntiles && !(a.ablate & 2)) fetch(t + 3 * G, r0, r1);
+        }
+        __syncthreads(); // B
+    };
+
+    for (int it = 0; t < a.ntiles; it += 2, t += 2 * G) {
+        iteration(it, t, s_tile0, s_tile1, ra0, ra1);
+        if (t + G < a.ntiles) iteration(it + 1, t + G, s_tile1, s_tile0, rb0, rb1);
     }
-    __syncthreads();
+
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
         const uint32_t c = s_cnt[i];
         if (c) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)c);
@@ -538,25 +653,50 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_filter_kernel(ApmFilterArgs a) 
 }
 
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a) {
-    return (size_t)a.tile_len + (size_t)((a.bytes_len + 15) & ~15) + (size_t)a.n_pats * (APM_FILTER_POS / 32) * 4 +
-           (size_t)a.n_pats * 4 + 16;
+    return 2 * (size_t)a.tile_len + (size_t)((a.bytes_len + 15) & ~15) + (size_t)a.nb * 16 + (size_t)a.nb * 8 +
+           (size_t)((a.n_ovf + 1) & ~1) * 8 + (size_t)a.qcap * 4 + (size_t)((a.n_pats + 3) & ~3) * 4 + 16 + 16;
 }
 
-hipError_t apm_launch_filter(const ApmFilterArgs &a, hipStream_t s) {
-    const int64_t span = a.je - a.tile0;
-    if (span <= 0 || a.n_pats <= 0) return hipSuccess;
-    const int64_t nt = (span + a.tile_w - 1) / a.tile_w;
-    if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds = apm_filter_lds_bytes(a);
-    const dim3 g((unsigned)nt), b(APM_BLOCK);
-    switch (a.band) {
-    case 0: hipLaunchKernelGGL(apm_filter_kernel<0>, g, b, lds, s, a); break;
-    case 1: hipLaunchKernelGGL(apm_filter_kernel<1>, g, b, lds, s, a); break;
-    case 2: hipLaunchKernelGGL(apm_filter_kernel<2>, g, b, lds, s, a); break;
-    case 3: hipLaunchKernelGGL(apm_filter_kernel<3>, g, b, lds, s, a); break;
-    default: return hipErrorInvalidValue;
+template <int BAND>
+static const void *apm_filter_fn_kl(int kl, int stride) {
+    if (kl == 16 && stride == 16) return (const void *)apm_filter_kernel<BAND, 16, 16>;
+    if (kl == 8 && stride == 8) return (const void *)apm_filter_kernel<BAND, 8, 8>;
+    if (kl == 8 && stride == 1) return (const void *)apm_filter_kernel<BAND, 8, 1>;
+    return nullptr;
+}
+
+static const void *apm_filter_fn(int band, int kl, int stride) {
+    switch (band) {
+    case 0: return apm_filter_fn_kl<0>(kl, stride);
+    case 1: return apm_filter_fn_kl<1>(kl, stride);
+    case 2: return apm_filter_fn_kl<2>(kl, stride);
+    case 3: return apm_filter_fn_kl<3>(kl, stride);
+    default: return nullptr;
     }
-    return hipGetLastError();
+}
+
+// workgroups of the filter kernel resident per CU for this LDS budget (queried once per plan)
+int apm_filter_blocks_per_cu(int band, int kl, int stride, size_t lds) {
+    int per_cu = 0;
+    const void *fn = apm_filter_fn(band, kl, stride);
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, APM_BLOCK, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    return per_cu > 8 ? 8 : per_cu;
+}
+
+hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t s) {
+    if (a.ntiles <= 0 || a.n_pats <= 0) return hipSuccess;
+    const void *fn = apm_filter_fn(a.band, a.key_len, a.stride);
+    if (!fn) return hipErrorInvalidValue;
+    const size_t lds = apm_filter_lds_bytes(a);
+    const int64_t cap = max_blocks < 1 ? 1 : max_blocks; // persistent grid = resident workgroups
+    const int64_t nb = a.ntiles < cap ? a.ntiles : cap;
+    ApmFilterArgs args = a;
+    if (const char *e = getenv("APM_FILTER_ABLATE")) args.ablate = atoi(e); // measurement aid, results invalid
+    void *kargs[] = {&args};
+    return hipLaunchKernel(fn, dim3((unsigned)nb), dim3(APM_BLOCK), kargs, lds, s);
 }
 
 // ---------------------------------------------------------------------------

@@ -57,8 +57,15 @@ struct TiledLaunch {       // host description of one tiled scan launch
     std::vector<uint8_t> bytes;
     std::vector<uint32_t> tables;
     uint8_t lut[256];
-    std::vector<ApmKey> keys8, keys4; // BANDED
+    std::vector<ApmKey> keys;         // BANDED: sub-keys
+    std::vector<uint16_t> piece_off;  // BANDED: piece offsets, per pattern contiguous
+    std::vector<uint32_t> table;      // BANDED: nb x 4 tags
+    std::vector<uint16_t> table_kid;  // BANDED: nb x 4 key ids
+    std::vector<uint32_t> ovf;        // BANDED: {fp, kid} pairs
+    int key_len = 0, stride = 0;      // BANDED: (16,16), (8,8) or (8,1)
+    int nb = 0, lg_nb = 0, qcap = 0;
     int a_max = 0;                    // BANDED: largest key offset
+    int blocks_per_cu = 0;            // BANDED: resident workgroups per CU (occupancy query, cached)
     int m_max = 0, m_min = 0, tile = 0;
     double cells_per_pos = 0; // sum m^2 over its patterns
 };
@@ -73,12 +80,16 @@ struct DevTiled {
     uint8_t *d_bytes = nullptr;
     uint32_t *d_tables = nullptr;
     uint8_t *d_lut = nullptr;
-    ApmKey *d_keys8 = nullptr;
-    ApmKey *d_keys4 = nullptr;
+    ApmKey *d_keys = nullptr;
+    uint16_t *d_piece_off = nullptr;
+    uint32_t *d_table = nullptr;
+    uint16_t *d_table_kid = nullptr;
+    uint32_t *d_ovf = nullptr;
 };
 
 struct DeviceState {
     int dev = -1;
+    int n_cu = 256;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     uint8_t *d_allpat = nullptr;              // every pattern's raw bytes, concatenated
@@ -171,7 +182,7 @@ int wavefront_rows_per_lane(int m) {
 int resolve_kernel(int forced, int m, int k, std::string *why) {
     if (forced == APM_KERNEL_AUTO) {
         if (k >= m) return KERNEL_TRIVIAL;
-        if (m <= APM_BANDED_MAX_M && k <= APM_BANDED_MAX_K && m / (k + 1) >= 4) return APM_KERNEL_BANDED;
+        if (m <= APM_BANDED_MAX_M && k <= APM_BANDED_MAX_K && m / (k + 1) >= APM_BANDED_MIN_PIECE) return APM_KERNEL_BANDED;
         if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR;
         return APM_KERNEL_GENERIC;
     }
@@ -184,8 +195,8 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
         if (m > APM_BITPAR_MAX_M) { *why = "BITPAR kernel supports pattern length <= 128"; return -100; }
         return APM_KERNEL_BITPAR;
     case APM_KERNEL_BANDED:
-        if (m > APM_BANDED_MAX_M || k > APM_BANDED_MAX_K || m / (k + 1) < 4) {
-            *why = "BANDED kernel needs m <= 256, k <= 7 and m/(k+1) >= 4 (pigeonhole keys of >= 4 bytes)";
+        if (m > APM_BANDED_MAX_M || k > APM_BANDED_MAX_K || m / (k + 1) < APM_BANDED_MIN_PIECE) {
+            *why = "BANDED kernel needs m <= 256, k <= 7 and m/(k+1) >= 8 (pigeonhole keys of 8 bytes)";
             return -100;
         }
         return APM_KERNEL_BANDED;
@@ -200,8 +211,11 @@ void free_device_plan(DeviceState &ds) {
         if (t.d_bytes) hipFree(t.d_bytes);
         if (t.d_tables) hipFree(t.d_tables);
         if (t.d_lut) hipFree(t.d_lut);
-        if (t.d_keys8) hipFree(t.d_keys8);
-        if (t.d_keys4) hipFree(t.d_keys4);
+        if (t.d_keys) hipFree(t.d_keys);
+        if (t.d_piece_off) hipFree(t.d_piece_off);
+        if (t.d_table) hipFree(t.d_table);
+        if (t.d_table_kid) hipFree(t.d_table_kid);
+        if (t.d_ovf) hipFree(t.d_ovf);
     }
     ds.tiled.clear();
     if (ds.d_allpat) hipFree(ds.d_allpat), ds.d_allpat = nullptr;
@@ -340,39 +354,57 @@ int build_plan(apm_ctx *ctx) {
         }
     }
 
-    // ---- BANDED launches: up to 64 patterns; k+1 pigeonhole keys per pattern ----
-    {
+    // ---- BANDED launches: patterns grouped by (key length, sampling stride); k+1 pigeonhole pieces each ----
+    for (int cls = 0; cls < 3; ++cls) {
+        const int klen = cls == 0 ? 16 : 8;
+        const int stride = cls == 0 ? 16 : (cls == 1 ? 8 : 1);
+        auto class_of = [&](int m) {
+            const int piece = m / (ctx->k + 1);
+            return piece >= 31 ? 0 : (piece >= 15 ? 1 : 2);
+        };
         std::vector<int> idx;
-        for (int i = 0; i < P; ++i) if (ctx->pats[i].kernel == APM_KERNEL_BANDED) idx.push_back(i);
+        for (int i = 0; i < P; ++i)
+            if (ctx->pats[i].kernel == APM_KERNEL_BANDED && class_of(ctx->pats[i].m) == cls) idx.push_back(i);
+        auto dword = [](const unsigned char *b) {
+            return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        };
+        auto fp8 = [](uint32_t lo, uint32_t hi) { return lo + (hi << 3); };
+        auto slot_hash = [](uint32_t f) { return (uint32_t)((uint64_t)(f & 0xffffffu) * 0x9E3779u) + (f >> 11); };
         for (size_t pos = 0; pos < idx.size();) {
             TiledLaunch L;
             L.kind = APM_KERNEL_BANDED;
+            L.key_len = klen;
+            L.stride = stride;
+            L.qcap = stride == 1 ? 4096 : 1024;
             memset(L.lut, 0, sizeof L.lut);
-            for (; pos < idx.size() && L.descs.size() < APM_BANDED_MAX_PATS; ++pos) {
+            const int pieces = ctx->k + 1;
+            for (; pos < idx.size(); ++pos) {
                 const PatternInfo &pi = ctx->pats[idx[pos]];
+                if (!L.descs.empty() && (L.bytes.size() + (size_t)pi.m > 16384 ||
+                                         L.keys.size() + (size_t)pieces * stride > 4096 || L.descs.size() >= 1024))
+                    break;
                 ApmPatDesc d{};
                 d.m = (uint32_t)pi.m;
                 d.index = (uint32_t)idx[pos];
                 d.byte_off = (uint32_t)L.bytes.size();
+                d.aux_off = (uint32_t)L.piece_off.size();
+                d.w = (uint32_t)pieces;
                 L.bytes.insert(L.bytes.end(), pi.bytes.begin(), pi.bytes.end());
-                const int pieces = ctx->k + 1;
-                const int lk = (pi.m / pieces >= 8) ? 8 : 4;
                 for (int q = 0; q < pieces; ++q) {
                     const int aq = (int)((int64_t)q * pi.m / pieces);
-                    const unsigned char *b = (const unsigned char *)pi.bytes.data() + aq;
-                    const uint32_t lo = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
-                    ApmKey key{};
-                    key.pat = (uint16_t)L.descs.size();
-                    key.off = (uint16_t)aq;
-                    if (lk == 8) {
-                        const uint32_t hi = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
-                        key.fp = lo ^ ((hi << 3) | (hi >> 29));
-                        L.keys8.push_back(key);
-                    } else {
-                        key.fp = lo;
-                        L.keys4.push_back(key);
+                    L.piece_off.push_back((uint16_t)aq);
+                    for (int r = 0; r < stride; ++r) {
+                        const unsigned char *b = (const unsigned char *)pi.bytes.data() + aq + r;
+                        ApmKey key{};
+                        key.pat = (uint16_t)L.descs.size();
+                        key.off = (uint16_t)(aq + r);
+                        key.piece = (uint16_t)q;
+                        key.next = 0;
+                        if (klen == 8) key.fp = fp8(dword(b), dword(b + 4));
+                        else key.fp = fp8(dword(b), dword(b + 4)) + (fp8(dword(b + 8), dword(b + 12)) & 0xffffffu) * 0x9E3779u;
+                        L.keys.push_back(key);
+                        L.a_max = std::max(L.a_max, aq + r);
                     }
-                    L.a_max = std::max(L.a_max, aq);
                 }
                 L.descs.push_back(d);
                 L.m_max = std::max(L.m_max, pi.m);
@@ -382,6 +414,44 @@ int build_plan(apm_ctx *ctx) {
             const int band = ctx->k / 2;
             const int front = band > 0 ? 16 : 0;
             L.tile = (APM_FILTER_POS - front - L.a_max - band) & ~31;
+            while (L.bytes.size() % 16) L.bytes.push_back(0);
+            // hash table: 4-way buckets of fingerprint tags, keys with equal fingerprints chained
+            int nb = 16, lg = 4;
+            while (nb < (int)L.keys.size() && nb < 2048) { nb *= 2; ++lg; }
+            for (;;) {
+                L.table.assign((size_t)nb * 4, APM_TAG_EMPTY);
+                L.table_kid.assign((size_t)nb * 4, 0);
+                L.ovf.clear();
+                std::vector<int> fill((size_t)nb, 0);
+                for (auto &kk : L.keys) kk.next = 0;
+                for (size_t kid = 0; kid < L.keys.size(); ++kid) {
+                    const uint32_t f = L.keys[kid].fp;
+                    const uint32_t slot = slot_hash(f) >> (32 - lg);
+                    int head = -1;
+                    for (int wv = 0; wv < fill[slot]; ++wv)
+                        if (L.table[slot * 4 + wv] == f) head = L.table_kid[slot * 4 + wv];
+                    if (head < 0)
+                        for (size_t o = 0; o + 1 < L.ovf.size(); o += 2)
+                            if (L.ovf[o] == f) head = (int)L.ovf[o + 1];
+                    if (head >= 0) { // chain behind the existing entry with this fingerprint
+                        int tail = head;
+                        while (L.keys[tail].next) tail = L.keys[tail].next - 1;
+                        L.keys[tail].next = (uint16_t)(kid + 1);
+                    } else if (fill[slot] < 4) {
+                        L.table[slot * 4 + fill[slot]] = f;
+                        L.table_kid[slot * 4 + fill[slot]] = (uint16_t)kid;
+                        ++fill[slot];
+                    } else {
+                        L.ovf.push_back(f);
+                        L.ovf.push_back((uint32_t)kid);
+                    }
+                }
+                if (L.ovf.size() / 2 <= 4 || nb >= 2048) break;
+                nb *= 2;
+                ++lg;
+            }
+            L.nb = nb;
+            L.lg_nb = lg;
             ctx->tiled.push_back(std::move(L));
         }
     }
@@ -404,8 +474,11 @@ int build_plan(apm_ctx *ctx) {
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_tables, L.tables))) return rc;
             std::vector<uint8_t> lut(L.lut, L.lut + 256);
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_lut, lut))) return rc;
-            if ((rc = upload_vec(ctx, &ds.tiled[t].d_keys8, L.keys8))) return rc;
-            if ((rc = upload_vec(ctx, &ds.tiled[t].d_keys4, L.keys4))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_keys, L.keys))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_piece_off, L.piece_off))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_table, L.table))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_table_kid, L.table_kid))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_ovf, L.ovf))) return rc;
         }
     }
     return APM_OK;
@@ -484,6 +557,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             ApmFilterArgs f{};
             f.text = d_text;
             f.avail = avail;
+            f.avail_pad = avail + (int64_t)((16u - ((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)avail) & 15u)) & 15u);
             f.jb = jb;
             f.je = je_l;
             f.nrel = nrel;
@@ -492,17 +566,28 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.tile0 = jb - (int64_t)((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)jb - (uintptr_t)f.front) & 15u);
             f.pats = ds.tiled[t].d_descs;
             f.bytes = ds.tiled[t].d_bytes;
-            f.keys8 = ds.tiled[t].d_keys8;
-            f.keys4 = ds.tiled[t].d_keys4;
+            f.keys = ds.tiled[t].d_keys;
+            f.piece_off = ds.tiled[t].d_piece_off;
+            f.table = reinterpret_cast<const uint4 *>(ds.tiled[t].d_table);
+            f.table_kid = ds.tiled[t].d_table_kid;
+            f.ovf = ds.tiled[t].d_ovf;
+            f.nk = (int)L.keys.size();
+            f.nb = L.nb;
+            f.lg_nb = L.lg_nb;
+            f.n_ovf = (int)(L.ovf.size() / 2);
+            f.qcap = L.qcap;
+            f.key_len = L.key_len;
+            f.stride = L.stride;
             f.counts = d_counts;
             f.n_pats = (int)L.descs.size();
-            f.n8 = (int)L.keys8.size();
-            f.n4 = (int)L.keys4.size();
             f.k = ctx->k;
             f.tile_w = L.tile;
-            f.tile_len = (std::max(APM_FILTER_POS + 24, f.front + L.tile + L.m_max) + 15) & ~15;
+            f.tile_len = (std::max(APM_FILTER_POS + 32, f.front + L.tile + L.m_max + 16) + 15) & ~15;
             f.bytes_len = (int)L.bytes.size();
-            HIP_TRY(ctx, apm_launch_filter(f, ds.stream));
+            f.ntiles = (je_l - f.tile0 + L.tile - 1) / L.tile;
+            if (!ctx->tiled[t].blocks_per_cu)
+                ctx->tiled[t].blocks_per_cu = apm_filter_blocks_per_cu(f.band, f.key_len, f.stride, apm_filter_lds_bytes(f));
+            HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * L.blocks_per_cu, ds.stream));
             ds.launches++;
             continue;
         }
@@ -702,6 +787,8 @@ int ensure_text(apm_ctx *ctx, DeviceState &ds, size_t bytes) {
 int init_device(apm_ctx *ctx, DeviceState &ds, int dev) {
     ds.dev = dev;
     HIP_TRY(ctx, hipSetDevice(dev));
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) ds.n_cu = ncu;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ds.own_stream, hipStreamNonBlocking));
     ds.stream = ds.own_stream;
     HIP_TRY(ctx, hipEventCreate(&ds.ev_start));
