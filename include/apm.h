@@ -160,6 +160,9 @@ void apm_synth_fill_host(uint8_t *dst, uint64_t global_off, uint64_t len, uint64
 int apm_count_synthetic(apm_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *counts);
 
 /* ---- introspection ---- */
+/* apm_count_shard_device brackets its kernels with hipEventRecord on the stream (what
+ * apm_get_timing reports).  enabled=0 drops those records from the launch path. */
+int apm_set_timing(apm_ctx *ctx, int enabled);
 int apm_get_timing(const apm_ctx *ctx, apm_timing *out);
 /* Kernel variant AUTO (or the forced variant) resolves to for pattern i. */
 int apm_pattern_kernel(const apm_ctx *ctx, int i);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "apm_device_count", "apm_abi_version", "apm_create", "apm_create_on_device", "apm_destroy",
     "apm_last_error", "apm_set_stream", "apm_set_patterns", "apm_set_kernel", "apm_count_buffer",
     "apm_count_file", "apm_count_shard_device", "apm_shard_range", "apm_synth_fill_device",
-    "apm_synth_fill_host", "apm_count_synthetic", "apm_get_timing", "apm_pattern_kernel",
+    "apm_synth_fill_host", "apm_count_synthetic", "apm_set_timing", "apm_get_timing", "apm_pattern_kernel",
     "apm_device_alloc", "apm_device_free", "apm_device_upload", "apm_device_download",
     "apm_device_memset", "apm_synchronize",
 ]
@@ -84,6 +84,7 @@ def load_library():
         "apm_synth_fill_device": (i32, [vp, vp, u64, u64, u64]),
         "apm_synth_fill_host": (None, [vp, u64, u64, u64]),
         "apm_count_synthetic": (i32, [vp, u64, u64, c.POINTER(u64)]),
+        "apm_set_timing": (i32, [vp, i32]),
         "apm_get_timing": (i32, [vp, c.POINTER(ApmTiming)]),
         "apm_pattern_kernel": (i32, [vp, i32]),
         "apm_device_alloc": (i32, [vp, c.POINTER(vp), u64]),
@@ -203,6 +204,9 @@ class ApmContext:
 
     def synth_fill_device(self, d_dst, global_off, length, seed):
         self._check(self._lib.apm_synth_fill_device(self._ctx, ctypes.c_void_p(d_dst), global_off, length, seed))
+
+    def set_timing(self, enabled):
+        self._check(self._lib.apm_set_timing(self._ctx, 1 if enabled else 0))
 
     def timing(self):
         t = ApmTiming()

@@ -63,6 +63,15 @@ struct ApmGenericArgs {
     unsigned long long *counts;
 };
 
+struct ApmTailArgs {       /* truncated tail windows of patterns with m <= 128 */
+    const uint8_t *text;
+    int64_t jb, je, nrel;
+    const ApmPatDesc *pats;
+    const uint8_t *bytes;
+    unsigned long long *counts;
+    int k;
+};
+
 /* BANDED (filter + verify) launch.  A key is a KL-byte sub-block of one of the k+1 disjoint
  * pieces of a pattern; `off` is its offset inside the pattern (piece offset + r). */
 struct ApmKey {
@@ -101,18 +110,12 @@ struct ApmFilterArgs {
     int tile_len;          /* bytes staged per tile (multiple of 16) */
     int bytes_len;
     int ablate;            /* measurement aid (APM_FILTER_ABLATE); 0 in production */
+    int n_main_blocks;     /* set by the launcher: persistent scan workgroups */
+    int n_tail;            /* extra workgroups, one per tail pattern (0: tails launched separately) */
+    ApmTailArgs tail;
 };
 
 #define APM_TAG_EMPTY 0x5bd1e995u
-
-struct ApmTailArgs {       /* truncated tail windows of patterns with m <= 128 */
-    const uint8_t *text;
-    int64_t jb, je, nrel;
-    const ApmPatDesc *pats;
-    const uint8_t *bytes;
-    unsigned long long *counts;
-    int k;
-};
 
 /* launchers (apm_kernels.hip) */
 hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t s);

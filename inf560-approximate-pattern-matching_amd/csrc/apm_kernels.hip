@@ -384,6 +384,58 @@ hipError_t apm_launch_synth(uint8_t *dst, uint64_t global_off, uint64_t len, uin
 }
 
 // ---------------------------------------------------------------------------
+// TAIL: the <= m-1 truncated windows at the very end of the text
+// (sequential.c:131-134: window AND pattern cut to size = n - j), m <= 128.
+// One 128-lane workgroup per pattern; each lane runs the 4-word bit-vector
+// column for `size` steps over an Eq table built in LDS.
+// ---------------------------------------------------------------------------
+// body shared by apm_tail_kernel and by the extra workgroups of the BANDED launch;
+// needs >= 128 threads, uses lanes 0..127; s_eq = 256 uint4 of LDS
+__device__ __forceinline__ void apm_tail_body(const ApmTailArgs &a, int pat_slot, uint4 *s_eq, int tid) {
+    const ApmPatDesc d = a.pats[pat_slot];
+    const int m = (int)d.m;
+    const uint8_t *pat = a.bytes + d.byte_off;
+    uint32_t *eqw = reinterpret_cast<uint32_t *>(s_eq);
+    uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_eq + 256); // last <= 128 text bytes
+    for (int i = tid; i < 1024; i += 128) eqw[i] = 0u;
+    const int64_t first_trunc = max(a.jb, a.nrel - m + 1);
+    const int64_t t0 = a.nrel - 128 > 0 ? a.nrel - 128 : 0; // stage the end of the text once
+    if (tid < 128) s_txt[tid] = (t0 + tid < a.nrel) ? a.text[t0 + tid] : (uint8_t)0;
+    __syncthreads();
+    if (tid < m) atomicOr(&eqw[(int)pat[tid] * 4 + (tid >> 5)], 1u << (tid & 31));
+    __syncthreads();
+    if (tid < 128) {
+        const int64_t j = first_trunc + tid;
+        const bool valid = j < a.je;
+        const int size = valid ? (int)(a.nrel - j) : 0; // 1 .. m-1 (<= 127)
+        const int lo = valid ? (int)(j - t0) : 0;
+        uint32_t pv[4], mv[4];
+        bp_init<4>(pv, mv);
+        for (int x = 0; x < m - 1; ++x) {
+            if (x < size) {
+                const uint4 v = s_eq[s_txt[lo + x]];
+                const uint32_t eq[4] = {v.x, v.y, v.z, v.w};
+                bp_step<4>(pv, mv, eq);
+            }
+        }
+        const bool hit = valid && bp_distance<4>(pv, mv, size, size) <= a.k;
+        const uint32_t cnt = apm_wave_count(hit);
+        if ((tid & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
+    }
+}
+
+__global__ __launch_bounds__(128) void apm_tail_kernel(ApmTailArgs a) {
+    __shared__ uint4 s_eq[256 + 8];
+    apm_tail_body(a, (int)blockIdx.x, s_eq, (int)threadIdx.x);
+}
+
+hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s) {
+    if (n_pats <= 0 || a.je <= a.jb) return hipSuccess;
+    hipLaunchKernelGGL(apm_tail_kernel, dim3((unsigned)n_pats), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // BANDED: exact shortcut for the predicate dist <= k.
 //
 // (1) Equal-length global alignment with <= k edits has #ins == #del <= k/2, so
@@ -479,6 +531,10 @@ template <int BAND, int KL, int STRIDE>
 __global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : 6) void apm_filter_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= a.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
+        apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
+        return;
+    }
     uint8_t *s_tile0 = smem;
     uint8_t *s_tile1 = smem + a.tile_len;
     uint8_t *s_pat = s_tile1 + a.tile_len;
@@ -511,7 +567,7 @@ __global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : 6) void 
         if (second) *reinterpret_cast<u32x4 *>(buf + 16 * (tid + APM_BLOCK)) = r1;
     };
 
-    const int64_t G = gridDim.x;
+    const int64_t G = a.n_main_blocks;
     int64_t t = blockIdx.x;
     u32x4 ra0 = {0, 0, 0, 0}, ra1 = {0, 0, 0, 0}, rb0 = {0, 0, 0, 0}, rb1 = {0, 0, 0, 0};
     if (t < a.ntiles) fetch(t, ra0, ra1);
@@ -652,7 +708,7 @@ __global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : 6) void 
     }
 }
 
-size_t apm_filter_lds_bytes(const ApmFilterArgs &a) {
+size_t apm_filter_lds_bytes(const ApmFilterArgs &a) { // always >= 4352 B, which the tail workgroups need
     return 2 * (size_t)a.tile_len + (size_t)((a.bytes_len + 15) & ~15) + (size_t)a.nb * 16 + (size_t)a.nb * 8 +
            (size_t)((a.n_ovf + 1) & ~1) * 8 + (size_t)a.qcap * 4 + (size_t)((a.n_pats + 3) & ~3) * 4 + 16 + 16;
 }
@@ -694,48 +750,9 @@ hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t
     const int64_t cap = max_blocks < 1 ? 1 : max_blocks; // persistent grid = resident workgroups
     const int64_t nb = a.ntiles < cap ? a.ntiles : cap;
     ApmFilterArgs args = a;
+    args.n_main_blocks = (int)nb;
     if (const char *e = getenv("APM_FILTER_ABLATE")) args.ablate = atoi(e); // measurement aid, results invalid
     void *kargs[] = {&args};
-    return hipLaunchKernel(fn, dim3((unsigned)nb), dim3(APM_BLOCK), kargs, lds, s);
+    return hipLaunchKernel(fn, dim3((unsigned)(nb + a.n_tail)), dim3(APM_BLOCK), kargs, lds, s);
 }
 
-// ---------------------------------------------------------------------------
-// TAIL: the <= m-1 truncated windows at the very end of the text
-// (sequential.c:131-134: window AND pattern cut to size = n - j), m <= 128.
-// One 128-lane workgroup per pattern; each lane runs the 4-word bit-vector
-// column for `size` steps over an Eq table built in LDS.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void apm_tail_kernel(ApmTailArgs a) {
-    __shared__ uint4 s_eq[256];
-    const ApmPatDesc d = a.pats[blockIdx.x];
-    const int m = (int)d.m;
-    const uint8_t *pat = a.bytes + d.byte_off;
-    const int tid = threadIdx.x;
-    uint32_t *eqw = reinterpret_cast<uint32_t *>(s_eq);
-    for (int i = tid; i < 1024; i += 128) eqw[i] = 0u;
-    __syncthreads();
-    if (tid < m) atomicOr(&eqw[(int)pat[tid] * 4 + (tid >> 5)], 1u << (tid & 31));
-    __syncthreads();
-    const int64_t first_trunc = max(a.jb, a.nrel - m + 1);
-    const int64_t j = first_trunc + tid;
-    const bool valid = j < a.je;
-    const int size = valid ? (int)(a.nrel - j) : 0; // 1 .. m-1
-    uint32_t pv[4], mv[4];
-    bp_init<4>(pv, mv);
-    for (int x = 0; x < m - 1; ++x) {
-        if (x < size) {
-            const uint4 v = s_eq[a.text[j + x]];
-            const uint32_t eq[4] = {v.x, v.y, v.z, v.w};
-            bp_step<4>(pv, mv, eq);
-        }
-    }
-    const bool hit = valid && bp_distance<4>(pv, mv, size, size) <= a.k;
-    const uint32_t cnt = apm_wave_count(hit);
-    if ((tid & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
-}
-
-hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s) {
-    if (n_pats <= 0 || a.je <= a.jb) return hipSuccess;
-    hipLaunchKernelGGL(apm_tail_kernel, dim3((unsigned)n_pats), dim3(128), 0, s, a);
-    return hipGetLastError();
-}

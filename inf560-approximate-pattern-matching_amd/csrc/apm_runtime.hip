@@ -135,6 +135,7 @@ struct apm_ctx {
     int kernel = APM_KERNEL_AUTO;
     int m_max = 0; // over non-trivial patterns
     bool patterns_set = false;
+    bool timing_on = true;   // hipEvent bracketing of every call (apm_set_timing)
     std::string err;
     apm_timing timing{};
     RcclApi rccl;
@@ -548,7 +549,22 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     const int64_t nrel = (int64_t)(n_total - text_off), avail = (int64_t)text_len;
     ds.text_bytes += need_end - ob;
 
-    HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
+    // truncated tail windows of the m <= 128 patterns (only the shard owning the end of the text has
+    // any): they ride as extra workgroups of the first BANDED launch, else get their own small launch
+    ApmTailArgs ta{};
+    bool tails_pending = !ctx->stails.descs.empty() && nrel - (int64_t)ctx->stails.m_max + 1 < je;
+    if (tails_pending) {
+        ta.text = d_text;
+        ta.jb = jb;
+        ta.je = je;
+        ta.nrel = nrel;
+        ta.pats = ds.d_stail_descs;
+        ta.bytes = ds.d_allpat;
+        ta.counts = d_counts;
+        ta.k = ctx->k;
+    }
+
+    if (ctx->timing_on) HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
     for (size_t t = 0; t < ctx->tiled.size(); ++t) {
         const TiledLaunch &L = ctx->tiled[t];
         const int64_t je_l = std::min<int64_t>(je, nrel - L.m_min + 1);
@@ -587,6 +603,11 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.ntiles = (je_l - f.tile0 + L.tile - 1) / L.tile;
             if (!ctx->tiled[t].blocks_per_cu)
                 ctx->tiled[t].blocks_per_cu = apm_filter_blocks_per_cu(f.band, f.key_len, f.stride, apm_filter_lds_bytes(f));
+            if (tails_pending) {
+                f.n_tail = (int)ctx->stails.descs.size();
+                f.tail = ta;
+                tails_pending = false;
+            }
             HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * L.blocks_per_cu, ds.stream));
             ds.launches++;
             continue;
@@ -615,22 +636,12 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     }
     int rc = launch_generic_group(ctx, ds, ctx->longs, ds.d_long_descs, 2, d_text, avail, jb, je, nrel, d_counts);
     if (rc) return rc;
-    HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
-    // truncated tail windows (only the shard owning the end of the text has any)
+    if (ctx->timing_on) HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
     if (!ctx->tails.descs.empty() && nrel - (int64_t)ctx->tails.m_max + 1 < je) {
         rc = launch_generic_group(ctx, ds, ctx->tails, ds.d_tail_descs, 1, d_text, avail, jb, je, nrel, d_counts);
         if (rc) return rc;
     }
-    if (!ctx->stails.descs.empty() && nrel - (int64_t)ctx->stails.m_max + 1 < je) {
-        ApmTailArgs ta{};
-        ta.text = d_text;
-        ta.jb = jb;
-        ta.je = je;
-        ta.nrel = nrel;
-        ta.pats = ds.d_stail_descs;
-        ta.bytes = ds.d_allpat;
-        ta.counts = d_counts;
-        ta.k = ctx->k;
+    if (tails_pending) {
         HIP_TRY(ctx, apm_launch_tail(ta, (int)ctx->stails.descs.size(), ds.stream));
         ds.launches++;
     }
@@ -808,6 +819,9 @@ int count_sharded(apm_ctx *ctx, uint64_t n, uint64_t *counts, Stage stage) {
     if (!counts) return fail(ctx, APM_ERR_INVALID, "counts is NULL");
     const auto t0 = clk::now();
     begin_call(ctx);
+    const bool timing_saved = ctx->timing_on;
+    ctx->timing_on = true; // the host-level calls synchronise anyway; keep their event times
+    struct Restore { apm_ctx *c; bool v; ~Restore() { c->timing_on = v; } } restore{ctx, timing_saved};
     const int G = (int)ctx->devs.size();
     const int P = (int)ctx->pats.size();
     const uint64_t halo = (uint64_t)std::max(ctx->m_max, 1) - 1;
@@ -955,6 +969,12 @@ int apm_set_patterns(apm_ctx *ctx, int n_patterns, const char *const *pat, const
     return APM_OK;
 }
 
+int apm_set_timing(apm_ctx *ctx, int enabled) {
+    if (!ctx) return APM_ERR_INVALID;
+    ctx->timing_on = enabled != 0;
+    return APM_OK;
+}
+
 int apm_set_kernel(apm_ctx *ctx, int kernel) {
     if (!ctx) return APM_ERR_INVALID;
     if (kernel < APM_KERNEL_AUTO || kernel > APM_KERNEL_BANDED) return fail(ctx, APM_ERR_INVALID, "unknown kernel variant %d", kernel);
@@ -1005,13 +1025,17 @@ int apm_count_shard_device(apm_ctx *ctx, const void *d_text, uint64_t text_off, 
     begin_call(ctx);
     DeviceState &ds = ctx->devs[0];
     HIP_TRY(ctx, hipSetDevice(ds.dev));
-    HIP_TRY(ctx, hipEventRecord(ds.ev_start, ds.stream));
-    HIP_TRY(ctx, hipEventRecord(ds.ev_kstart, ds.stream));
+    if (ctx->timing_on) {
+        HIP_TRY(ctx, hipEventRecord(ds.ev_start, ds.stream));
+        HIP_TRY(ctx, hipEventRecord(ds.ev_kstart, ds.stream));
+    }
     const int rc = scan_shard(ctx, ds, (const uint8_t *)d_text, text_off, text_len, n_total, own_begin, own_end,
                               (unsigned long long *)d_counts);
     if (rc) return rc;
-    HIP_TRY(ctx, hipEventRecord(ds.ev_stop, ds.stream));
-    ds.events_recorded = true;
+    if (ctx->timing_on) {
+        HIP_TRY(ctx, hipEventRecord(ds.ev_stop, ds.stream));
+        ds.events_recorded = true;
+    }
     account(ctx, n_total, own_begin, own_end);
     return APM_OK;
 }
