@@ -193,6 +193,14 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = cells / (elapsed / args.steps)
     achieved_gbs = shard_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None   # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, profiles/traffic.json)
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            ent = json.load(f).get("%s:%s" % (args.config, "+".join(kernel_names)))
+        if ent and world == 1 and not args.bytes_per_gpu:
+            traffic = ent["traffic_bytes"]
+    except Exception:
+        traffic = None
     line = {
         "metric": "window-DP-cells/sec",
         "value": value,
@@ -214,7 +222,7 @@ def main():
         "counts_exact_vs_planted": bool(counts_ok),
         "event_ms_per_step": ev_ms / args.steps,
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "+".join(kernel_names), "kernel_ms_avg": kernel_ms, "launches_per_step": n_launch,
                      "algorithmic_bytes_per_launch": shard_bytes,
                      "note": "1 HBM byte per text position per launch (SURVEY 8d); the full DP is integer-VALU bound, see variants[].valu_frac"},
