@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--config", default="cfg2", help="workload: cfg2|cfg3|cfg4|cfg5 (per-GPU size = cfg n / its GPU count)")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--bytes-per-gpu", type=int, default=0, help="override the per-GPU text size")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     return ap.parse_args()
@@ -108,10 +109,14 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: this engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     cfg = wl.CONFIGS[args.config]
     k, lens, seed = cfg["k"], cfg["lens"], wl.seed_of(cfg["cid"])
@@ -124,7 +129,7 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)                      # one explicit HIP stream for everything
     torch.cuda.set_stream(stream)
-    ctx = apm.ApmContext(device=local_rank)
+    ctx = apm.ApmContext(device=dev_index)
     ctx.set_stream(stream.cuda_stream)                          # the library launches on torch's stream
     ctx.set_patterns(pats, k)
     ctx.set_kernel(args.kernel)
@@ -133,17 +138,39 @@ def main():
     ob, oe, lo, hi = sharding.rank_shard(n_total, k, m_max, rank, world)
     text = torch.empty(hi - lo + 16, dtype=torch.uint8, device=dev)
     ctx.synth_fill_device(text.data_ptr(), lo, hi - lo, seed)   # inputs resident in HBM
-    counts = torch.zeros(P, dtype=torch.int64, device=dev)
+    # two count vectors: the all-reduce of step i (RCCL's own stream) overlaps the scan of step i+1
+    ring = [torch.zeros(P, dtype=torch.int64, device=dev) for _ in range(2)]
+    pending = [None, None]
+    counts = ring[0]
     torch.cuda.synchronize()
 
-    def step():
-        counts.zero_()
-        ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, counts.data_ptr())
-        sharding.allreduce_counts(counts)                       # RCCL over xGMI, P x int64 (no-op at N=1)
+    def step(i):
+        b = i & 1
+        if pending[b] is not None:
+            pending[b].wait()                                   # buffer free again (stream-level wait)
+            pending[b] = None
+        c = ring[b]
+        c.zero_()
+        ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, c.data_ptr())
+        if world > 1:
+            if args.dist_backend == "nccl":
+                pending[b] = dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True)  # P x int64 over xGMI
+            else:
+                h = c.cpu()
+                sharding.allreduce_counts(h)
+                c.copy_(h)
+        return c
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     ctx.set_timing(False)       # no event records inside the timed region
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -151,8 +178,9 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        counts = step(i)
+    drain()
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -161,7 +189,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_counts = counts.cpu().tolist()
@@ -170,9 +198,10 @@ def main():
     # its scan kernels with hipEventRecord on the same stream), averaged over `steps` launches
     ctx.set_timing(True)
     kms = []
+    scratch = torch.zeros(P, dtype=torch.int64, device=dev)
     for _ in range(args.steps):
-        counts.zero_()
-        ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, counts.data_ptr())
+        scratch.zero_()
+        ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, scratch.data_ptr())
         tm = ctx.timing()
         kms.append(tm["main_kernel_ms"])
     kernel_ms = sum(kms) / len(kms)
@@ -238,12 +267,12 @@ def main():
             reps = 3
             ms = []
             for _ in range(reps + 1):
-                counts.zero_()
-                ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, counts.data_ptr())
+                scratch.zero_()
+                ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, scratch.data_ptr())
                 ms.append(ctx.timing()["main_kernel_ms"])
             ms = ms[1:]
             kms_v = sum(ms) / len(ms)
-            ok = counts.cpu().tolist() == final_counts
+            ok = scratch.cpu().tolist() == final_counts
             variants[name] = {"cells_evaluated_per_s": cells / (kms_v * 1e-3), "kernel_ms": kms_v,
                               "counts_equal_headline": bool(ok),
                               "hbm_frac": shard_bytes / (kms_v * 1e-3) / 1e9 / HBM_PEAK_GBS}
