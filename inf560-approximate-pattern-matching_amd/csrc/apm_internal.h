@@ -93,12 +93,12 @@ struct ApmFilterArgs {
     int64_t tile0;         /* first window start of tile 0; text+tile0-front is 16-byte aligned */
     int64_t ntiles;
     const ApmPatDesc *pats;/* m, byte_off (into bytes), index, aux_off = first entry in piece_off, w = pieces (k+1) */
-    const uint8_t *bytes;  /* raw pattern bytes of this launch (padded to 16) */
-    const ApmKey *keys;    /* nk sub-keys */
-    const uint16_t *piece_off; /* piece offsets a_q, per pattern contiguous */
-    const uint4 *table;    /* nb buckets x 4 fingerprint tags (empty = APM_TAG_EMPTY) */
-    const uint16_t *table_kid; /* nb x 4 key ids */
-    const uint32_t *ovf;   /* n_ovf x {fp, kid}: keys whose bucket was full */
+    const uint4 *image;    /* launch image, copied verbatim to LDS: pattern bytes at 0, then (all 16-byte aligned)
+                              o_tab: nb buckets x 8 16-bit tags (empty 0xffff); o_kid: nb x 8 16-bit key ids
+                              (empty 0xffff, bit 15 = head of a chain); o_ovf: n_ovf x {tag, kid16};
+                              o_kinfo: nk x (pat | off<<12 | piece<<21); o_pinfo: n_pats x {byte_off | m<<16, aux_off} */
+    int image_len, o_tab, o_kid, o_ovf, o_kinfo, o_pinfo, o_next, o_poff; /* o_next: nk x u16 chain links,
+                              o_poff: piece offsets a_q (u16), per pattern contiguous */
     unsigned long long *counts;
     int n_pats, nk;
     int nb, lg_nb, n_ovf;  /* hash table geometry */
@@ -107,9 +107,9 @@ struct ApmFilterArgs {
     int k, band;           /* band = k/2 */
     int tile_w;            /* window starts per workgroup tile (multiple of 32) */
     int front;             /* bytes staged in front of the first window (0 or 16) */
-    int tile_len;          /* bytes staged per tile (multiple of 16) */
-    int bytes_len;
+    int tile_len;          /* bytes staged per tile: APM_FILTER_POS (one 16-byte load per lane) */
     int ablate;            /* measurement aid (APM_FILTER_ABLATE); 0 in production */
+    int use_dma;           /* 1: LDS-DMA tile path (text pointer 16-byte aligned), 0: register-staged path */
     int n_main_blocks;     /* set by the launcher: persistent scan workgroups */
     int n_tail;            /* extra workgroups, one per tail pattern (0: tails launched separately) */
     ApmTailArgs tail;
@@ -121,7 +121,7 @@ struct ApmFilterArgs {
 hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t s);
 hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s);
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a);
-int apm_filter_blocks_per_cu(int band, int key_len, int stride, size_t lds);
+int apm_filter_blocks_per_cu(int band, int key_len, int stride, int dma, size_t lds);
 hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s);

@@ -468,6 +468,8 @@ hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s) {
 // Per launch the text is read from HBM exactly once (+ halo per tile).
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 apm_as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
 __device__ __forceinline__ uint32_t apm_fp8(uint32_t lo, uint32_t hi) {
     return lo + (hi << 3); // v_lshl_add_u32; injective on ACGT 8-mers (no carries between bytes)
@@ -476,17 +478,48 @@ __device__ __forceinline__ uint32_t apm_fp16(uint32_t f_lo, uint32_t f_hi) {
     return f_lo + __umul24(f_hi, 0x9E3779u); // v_mad_u32_u24: 16 text bytes -> 32 bits
 }
 __device__ __forceinline__ uint32_t apm_slot_hash(uint32_t f) {
-    return __umul24(f, 0x9E3779u) + (f >> 11); // bucket = top bits
+    return __umul24(f, 0x9E3779u) + __umul24(f >> 12, 0x85EBCAu); // bucket = top bits, tag = low 16 bits
 }
 
-__device__ __forceinline__ bool apm_bytes_equal(const uint8_t *x, const uint8_t *y, int n) {
-    for (int i = 0; i < n; ++i)
-        if (x[i] != y[i]) return false;
-    return true;
+// bucket = top bits, tag = low 16 bits.  A 16-byte fingerprint is already mixed by its mad24;
+// an 8-byte one (lo + hi*8, injective but structured) needs the extra multiply-mix.
+template <int KL>
+__device__ __forceinline__ uint32_t apm_table_hash(uint32_t f) {
+    if constexpr (KL == 16) return f;
+    else return apm_slot_hash(f);
 }
 
+// N dwords of bytes starting at (16-byte aligned LDS base) + off, any alignment of off:
+// N+1 aligned ds_read_b32 + N v_alignbyte -- no dependent byte loads
+template <int N>
+__device__ __forceinline__ void apm_lds_dwords(const uint8_t *base, int off, uint32_t (&out)[N]) {
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(base) + (off >> 2);
+    const uint32_t sh = (uint32_t)off & 3u;
+    uint32_t w[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) w[i] = a[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+}
+
+template <int KL>
+__device__ __forceinline__ bool apm_key_equal(const uint8_t *tb, int toff, const uint8_t *pb, int poff) {
+    uint32_t x[KL / 4], y[KL / 4];
+    apm_lds_dwords<KL / 4>(tb, toff, x);
+    apm_lds_dwords<KL / 4>(pb, poff, y);
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < KL / 4; ++i) d |= x[i] ^ y[i];
+    return d == 0u;
+}
+
+// Banded DP (|x-y| <= BAND) with early exit over window tb[toff..toff+m) vs pattern pb[poff..poff+m).
+// Columns 1..16 run out of registers (bytes fetched as dwords up front, statically indexed); most
+// candidates die there.  Needs m >= 16 + BAND for the register phase, otherwise byte loop only.
 template <int BAND>
-__device__ __forceinline__ bool apm_banded_verify(const uint8_t *t, const uint8_t *p, int m, int k) {
+__device__ __forceinline__ bool apm_banded_verify(const uint8_t *tb, int toff, const uint8_t *pb, int poff, int m,
+                                                  int k) {
+    const uint8_t *t = tb + toff, *p = pb + poff;
     if constexpr (BAND == 0) {
         int mism = 0;
         for (int x = 0; x < m; ++x) {
@@ -500,7 +533,36 @@ __device__ __forceinline__ bool apm_banded_verify(const uint8_t *t, const uint8_
         int e[NB]; // e[d+BAND] = cell(x, x+d)
 #pragma unroll
         for (int i = 0; i < NB; ++i) e[i] = (i >= BAND) ? (i - BAND) : INF; // cell(0, d) = d
-        for (int x = 1; x <= m; ++x) {
+        int x0 = 1;
+        if (m >= 16 + BAND) {
+            uint32_t T[4], P[5];
+            apm_lds_dwords<4>(tb, toff, T);
+            apm_lds_dwords<5>(pb, poff, P); // pattern bytes 0..19 (>= 16 + BAND - 1)
+#pragma unroll
+            for (int x = 1; x <= 16; ++x) {
+                const int tc = (int)((T[(x - 1) >> 2] >> (8 * ((x - 1) & 3))) & 0xffu);
+                int up = INF, best = INF;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int y = x + i - BAND; // static
+                    int nv;
+                    if (y < 1) {
+                        nv = (y == 0) ? x : INF;
+                    } else {
+                        const int pc = (int)((P[(y - 1) >> 2] >> (8 * ((y - 1) & 3))) & 0xffu);
+                        const int diag = e[i] + ((pc != tc) ? 1 : 0);
+                        const int left = (i + 1 < NB) ? e[i + 1] + 1 : INF;
+                        nv = apm_min3(diag, left, up + 1);
+                    }
+                    e[i] = nv;
+                    up = nv;
+                    best = min(best, nv);
+                }
+                if ((x & 3) == 0 && best > k) return false;
+            }
+            x0 = 17;
+        }
+        for (int x = x0; x <= m; ++x) {
             const int tc = (int)t[x - 1];
             int up = INF; // cell(x, y-1) of the previous diagonal at this x
             int best = INF;
@@ -527,30 +589,40 @@ __device__ __forceinline__ bool apm_banded_verify(const uint8_t *t, const uint8_
     }
 }
 
-template <int BAND, int KL, int STRIDE>
-__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : 6) void apm_filter_kernel(ApmFilterArgs a) {
+// DMA = 1: tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), three LDS
+// tile buffers, waits placed by hand (vmcnt(1): the younger tile stays in flight).  Needs a 16-byte
+// aligned text pointer.  DMA = 0: register-staged buffer loads, two LDS buffers, compiler-placed waits.
+template <int BAND, int KL, int STRIDE, int DMA>
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : 6))
+void apm_filter_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= a.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
+    // LDS: [tile 0 | tile 1 | (tile 2) | launch image (pattern bytes, hash table, key/pattern records) | queue | counts]
+    constexpr int NBUF = DMA ? 3 : 2;
     uint8_t *s_tile0 = smem;
     uint8_t *s_tile1 = smem + a.tile_len;
-    uint8_t *s_pat = s_tile1 + a.tile_len;
-    uint4 *s_tab = reinterpret_cast<uint4 *>(s_pat + ((a.bytes_len + 15) & ~15)); // nb buckets x 4 tags
-    uint16_t *s_kid = reinterpret_cast<uint16_t *>(s_tab + a.nb);                  // nb x 4 key ids
-    uint32_t *s_ovf = reinterpret_cast<uint32_t *>(s_kid + 4 * a.nb);              // n_ovf x {fp, kid}
-    uint32_t *s_queue = s_ovf + 2 * ((a.n_ovf + 1) & ~1);
-    uint32_t *s_cnt = s_queue + a.qcap;
-    uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [2]
+    uint8_t *s_img = smem + NBUF * a.tile_len;
+    uint8_t *s_pat = s_img;                                              // raw pattern bytes
+    uint4 *s_tab = reinterpret_cast<uint4 *>(s_img + a.o_tab);           // nb buckets x 8 16-bit tags
+    uint4 *s_kid = reinterpret_cast<uint4 *>(s_img + a.o_kid);           // nb x 8 16-bit key ids
+    uint32_t *s_ovf = reinterpret_cast<uint32_t *>(s_img + a.o_ovf);     // n_ovf x {tag, kid16}
+    uint32_t *s_kinfo = reinterpret_cast<uint32_t *>(s_img + a.o_kinfo); // nk: pat | off<<12 | piece<<21
+    uint2 *s_pinfo = reinterpret_cast<uint2 *>(s_img + a.o_pinfo);       // n_pats: {byte_off | m<<16, aux_off}
+    const uint16_t *s_next = reinterpret_cast<const uint16_t *>(s_img + a.o_next); // nk: chain links (id+1, 0 = end)
+    const uint16_t *s_poff = reinterpret_cast<const uint16_t *>(s_img + a.o_poff); // piece offsets a_q
+    uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_img + a.image_len); // 2 x qcap
+    uint32_t *s_cnt = s_queue + 2 * a.qcap;
+    uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [3] rotating queue counters
 
-    const int n16 = a.tile_len >> 4;
-    const bool second = tid + APM_BLOCK < n16;
-    // Branch-free tile fetch: raw buffer loads, the descriptor's num_records does the bounds
-    // check (out-of-range lanes return 0 and move no data), so the loads stay in flight across
-    // the processing of the previous tiles instead of being fenced by control flow.
-    auto fetch = [&](int64_t t, u32x4 &r0, u32x4 &r1) {
+    // Branch-free tile fetch: ONE raw buffer load of 16 bytes per lane per tile (tile = 4096 bytes),
+    // the descriptor's num_records does the bounds check (out-of-range lanes return 0 and move no
+    // data).  No other vector-memory operation lives in the tile loop, so the compiler's vmcnt
+    // bookkeeping keeps the younger prefetch in flight while the older one is consumed.
+    auto fetch = [&](int64_t t, u32x4 &r0) __attribute__((always_inline)) {
         const int64_t g = a.tile0 + t * a.tile_w - a.front; // >= -31
         const int64_t gb = g > 0 ? g : 0;
         const int64_t lim = a.avail_pad - gb;
@@ -558,71 +630,100 @@ __global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : 6) void 
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + gb, 0, (int)nrec, 0x00020000);
         const uint32_t o0 = (uint32_t)((int)(g - gb) + 16 * tid); // negative wraps -> out of range -> 0
-        const uint32_t o1 = second ? o0 + 16u * APM_BLOCK : 0xfffffff0u;
         r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0, 0, 0);
-        r1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o1, 0, 0);
     };
-    auto stash = [&](uint8_t *buf, const u32x4 &r0, const u32x4 &r1) {
+    auto stash = [&](uint8_t *buf, const u32x4 &r0) __attribute__((always_inline)) {
         *reinterpret_cast<u32x4 *>(buf + 16 * tid) = r0;
-        if (second) *reinterpret_cast<u32x4 *>(buf + 16 * (tid + APM_BLOCK)) = r1;
     };
 
     const int64_t G = a.n_main_blocks;
     int64_t t = blockIdx.x;
-    u32x4 ra0 = {0, 0, 0, 0}, ra1 = {0, 0, 0, 0}, rb0 = {0, 0, 0, 0}, rb1 = {0, 0, 0, 0};
-    if (t < a.ntiles) fetch(t, ra0, ra1);
-    for (int i = tid * 4; i < a.bytes_len; i += APM_BLOCK * 4) // pool is padded to 16 bytes
-        *reinterpret_cast<uint32_t *>(s_pat + i) = *reinterpret_cast<const uint32_t *>(a.bytes + i);
-    for (int i = tid; i < a.nb; i += APM_BLOCK) s_tab[i] = a.table[i];
-    for (int i = tid; i < 2 * a.nb; i += APM_BLOCK)
-        reinterpret_cast<uint32_t *>(s_kid)[i] = reinterpret_cast<const uint32_t *>(a.table_kid)[i];
-    for (int i = tid; i < 2 * a.n_ovf; i += APM_BLOCK) s_ovf[i] = a.ovf[i];
-    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
-    if (tid < 2) s_qn[tid] = 0u;
-    if (t < a.ntiles) {
-        stash(s_tile0, ra0, ra1);
-        if (t + G < a.ntiles) fetch(t + G, ra0, ra1);         // A: tile t+G   -> lands in buffer 1
-        if (t + 2 * G < a.ntiles) fetch(t + 2 * G, rb0, rb1); // B: tile t+2G -> lands in buffer 0
-    }
-    __syncthreads();
+    u32x4 ra0 = {0, 0, 0, 0}, rb0 = {0, 0, 0, 0};
 
-    // verification of one (key, sampled text position) nomination; bumps s_cnt
-    auto verify_entry = [&](const uint8_t *s_tile, int64_t base, int kid, int pos) {
-        const ApmKey key = a.keys[kid];
-        const ApmPatDesc d = a.pats[key.pat];
-        const uint8_t *pat = s_pat + d.byte_off;
-        if (!apm_bytes_equal(s_tile + pos, pat + key.off, KL)) return; // fingerprint collision
-        const int m = (int)d.m;
-        const int64_t je_p = min(a.je, a.nrel - m + 1);
-        for (int dl = -BAND; dl <= BAND; ++dl) {
-            const int jr = pos - a.front - (int)key.off - dl; // window start relative to base
-            const int64_t j = base + jr;
-            if (jr < 0 || jr >= a.tile_w || j < a.jb || j >= je_p) continue;
-            if (!apm_banded_verify<BAND>(s_tile + a.front + jr, pat, m, a.k)) continue;
-            // count the window once: only from its first true (piece, shift) nominator
-            bool first = true;
-            for (int qq = 0; qq <= (int)key.piece && first; ++qq) {
-                const int aq = (int)a.piece_off[d.aux_off + qq];
-                for (int dd = -BAND; dd <= BAND; ++dd) {
-                    if (qq == (int)key.piece && dd >= dl) break;
-                    const int o = a.front + jr + aq + dd;           // piece start under shift dd
-                    const int rr = (STRIDE - (o % STRIDE)) % STRIDE; // its sampled (aligned) block
-                    if (apm_bytes_equal(s_tile + o + rr, pat + aq + rr, KL)) {
-                        first = false;
-                        break;
-                    }
-                }
-            }
-            if (first) atomicAdd(&s_cnt[key.pat], 1u);
+    // LDS-DMA of one tile: lane L's 16 bytes land at (buffer + wave*1024) + 16*L.  Lanes outside the
+    // text read a clamped in-range address instead (their bytes are never part of a counted window).
+    const uint32_t lds0 = __builtin_amdgcn_groupstaticsize();
+    const uint32_t wave_off = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6) * 1024u;
+    const uint32_t lane_off = 16u * (uint32_t)tid;
+    auto dma = [&](int64_t tt, int buf) __attribute__((always_inline)) {
+        const int64_t gt = a.tile0 + tt * a.tile_w - a.front; // tile start (uniform)
+        const uint32_t base = lds0 + (uint32_t)buf * (uint32_t)APM_FILTER_POS + wave_off;
+        uint32_t keep;
+        if (gt >= 0 && gt + APM_FILTER_POS <= a.avail_pad) { // whole tile inside the text: scalar base + lane offset
+            const uint8_t *gbase = a.text + gt;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(lane_off), "s"(base), "s"(gbase)
+                         : "memory");
+        } else { // edge tile: clamp every lane's address into the text
+            int64_t g = gt + 16 * tid;
+            const int64_t hi = a.avail_pad - 16;
+            g = g > hi ? hi : g;
+            g = g < 0 ? 0 : g;
+            const uint8_t *gp = a.text + g;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gp), "s"(base)
+                         : "memory");
         }
+    };
+
+    if constexpr (DMA) {
+        for (int b = 0; b < 3; ++b)
+            if (t + b * G < a.ntiles) dma(t + b * G, b);
+    } else {
+        if (t < a.ntiles) fetch(t, ra0);
+    }
+    // the launch image is ONE contiguous blob laid out like its LDS copy: a single round of
+    // 16-byte loads, one wait (separate small copies would chain their HBM latencies)
+    for (int i = tid; i < (a.image_len >> 4); i += APM_BLOCK)
+        reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
+    if (tid < 3) s_qn[tid] = 0u;
+    if constexpr (!DMA) {
+        if (t < a.ntiles) {
+            stash(s_tile0, ra0);
+            if (t + G < a.ntiles) fetch(t + G, ra0);         // A: tile t+G   -> lands in buffer 1
+            if (t + 2 * G < a.ntiles) fetch(t + 2 * G, rb0); // B: tile t+2G -> lands in buffer 0
+        }
+    }
+    __syncthreads(); // (drains the prologue loads, DMA included)
+
+    // verification of one (key, sampled text position, shift) nomination; bumps s_cnt
+    auto verify_item = [&](const uint8_t *s_tile, int64_t base, int kid, int pos, int dl) __attribute__((always_inline)) {
+        const uint32_t ki = s_kinfo[kid];
+        struct { int pat, off, piece; } key = {(int)(ki & 0xfffu), (int)((ki >> 12) & 0x1ffu), (int)((ki >> 21) & 7u)};
+        const uint2 pinf = s_pinfo[key.pat];
+        struct { int m, aux_off; } d = {(int)(pinf.x >> 16), (int)pinf.y};
+        const int poff = (int)(pinf.x & 0xffffu);
+        if (!apm_key_equal<KL>(s_tile, pos, s_pat, poff + (int)key.off)) return; // fingerprint collision
+        const int m = d.m;
+        const int64_t je_p = min(a.je, a.nrel - m + 1);
+        const int jr = pos - a.front - key.off - dl; // window start relative to base
+        const int64_t j = base + jr;
+        if (jr < 0 || jr >= a.tile_w || j < a.jb || j >= je_p) return;
+        if (!apm_banded_verify<BAND>(s_tile, a.front + jr, s_pat, poff, m, a.k)) return;
+        // count the window once: only from its first true (piece, shift) nominator
+        for (int qq = 0; qq <= (int)key.piece; ++qq) {
+            const int aq = (int)s_poff[d.aux_off + qq];
+            for (int dd = -BAND; dd <= BAND; ++dd) {
+                if (qq == (int)key.piece && dd >= dl) break;
+                const int o = a.front + jr + aq + dd;           // piece start under shift dd
+                const int rr = (STRIDE - (o % STRIDE)) % STRIDE; // its sampled (aligned) block
+                if (apm_key_equal<KL>(s_tile, o + rr, s_pat, poff + aq + rr)) return;
+            }
+        }
+        atomicAdd(&s_cnt[key.pat], 1u);
     };
 
     const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
 
-    auto iteration = [&](int it, int64_t t, const uint8_t *s_tile, uint8_t *s_other, u32x4 &r0, u32x4 &r1) {
-        const int cur = it & 1;
-        const int64_t base = a.tile0 + t * a.tile_w; // first window start of the tile
-        const int p0 = tid * 16;                     // LDS offset of this lane's first position
+    // filter + enqueue, barrier, cooperative verification of tile t held in s_tile
+    // filter + enqueue of the tile held in s_tile: pushes (tag, position) into queue array `qa`
+    // (0/1) under counter s_qn[qc]
+    auto filter_tile = [&](const uint8_t *s_tile, int qa, int qc) __attribute__((always_inline)) {
+        const int p0 = tid * 16; // LDS offset of this lane's first position
+        uint32_t *queue = s_queue + qa * a.qcap;
 
         // ---- fingerprints of this lane's sampled positions ----
         constexpr int NF = 16 / STRIDE;
@@ -650,57 +751,113 @@ __global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : 6) void 
         if (!(a.ablate & 1)) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                const uint32_t fi = f[i];
-                const uint32_t slot = apm_slot_hash(fi) >> hshift;
-                const uint4 tg = s_tab[slot];
-                bool hit = (tg.x == fi) | (tg.y == fi) | (tg.z == fi) | (tg.w == fi);
-                for (int o = 0; o < a.n_ovf; ++o) hit |= (s_ovf[2 * o] == fi);
-                if (hit) { // rare with long keys
-                    auto push = [&](uint32_t kid) { // a table entry heads a chain of keys with equal fingerprint
-                        for (;;) {
-                            const uint32_t idx = atomicAdd(&s_qn[cur], 1u);
-                            if (idx < (uint32_t)a.qcap) s_queue[idx] = (kid << 16) | (uint32_t)(p0 + i * STRIDE);
-                            const uint32_t nxt = a.keys[kid].next;
-                            if (!nxt) break;
-                            kid = nxt - 1u;
-                        }
-                    };
-                    if (tg.x == fi) push(s_kid[4 * slot + 0]);
-                    if (tg.y == fi) push(s_kid[4 * slot + 1]);
-                    if (tg.z == fi) push(s_kid[4 * slot + 2]);
-                    if (tg.w == fi) push(s_kid[4 * slot + 3]);
-                    for (int o = 0; o < a.n_ovf; ++o)
-                        if (s_ovf[2 * o] == fi) push(s_ovf[2 * o + 1]);
+                const uint32_t h = apm_table_hash<KL>(f[i]);
+                const uint32_t slot = h >> hshift;
+                const uint32_t tag = h & 0xffffu;
+                const uint32_t rep = tag | (tag << 16);
+                const uint4 tg = s_tab[slot]; // 8 x 16-bit tags
+                const u16x2 m01 = __builtin_elementwise_min(apm_as_u16x2(tg.x ^ rep), apm_as_u16x2(tg.y ^ rep));
+                const u16x2 m23 = __builtin_elementwise_min(apm_as_u16x2(tg.z ^ rep), apm_as_u16x2(tg.w ^ rep));
+                const u16x2 mm = __builtin_elementwise_min(m01, m23); // v_pk_min_u16: a zero half = tag match
+                bool hit = (mm.x == 0) | (mm.y == 0);
+                for (int o = 0; o < a.n_ovf; ++o) hit |= (s_ovf[2 * o] == tag);
+                if (hit) { // rare with long keys: defer the bucket walk to the cooperative phase
+                    const uint32_t idx = atomicAdd(&s_qn[qc], 1u);
+                    if (idx < (uint32_t)a.qcap) queue[idx] = (tag << 16) | (uint32_t)(p0 + i * STRIDE);
                 }
             }
         }
-        __syncthreads(); // A: queue complete
-
-        // ---- verify ----
-        const uint32_t qn = s_qn[cur];
-        if (tid == 0) s_qn[cur ^ 1] = 0u; // next iteration's counter (nobody reads it before barrier B)
-        if (qn <= (uint32_t)a.qcap) {
-            for (uint32_t e = tid; e < qn; e += APM_BLOCK) {
-                const uint32_t ent = s_queue[e];
-                verify_entry(s_tile, base, (int)(ent >> 16), (int)(ent & 0xffffu));
-            }
-        } else { // queue overflow: dense pass over every (sampled position, key)
-            for (int i = 0; i < NF; ++i)
-                for (int kid = 0; kid < a.nk; ++kid) verify_entry(s_tile, base, kid, p0 + i * STRIDE);
-        }
-
-        // ---- land tile t+G in the other buffer, start fetching tile t+3G ----
-        if (t + G < a.ntiles) {
-            stash(s_other, r0, r1);
-            if (t + 3 * G < a.ntiles && !(a.ablate & 2)) fetch(t + 3 * G, r0, r1);
-        }
-        __syncthreads(); // B
     };
 
-    for (int it = 0; t < a.ntiles; it += 2, t += 2 * G) {
-        iteration(it, t, s_tile0, s_tile1, ra0, ra1);
-        if (t + G < a.ntiles) iteration(it + 1, t + G, s_tile1, s_tile0, rb0, rb1);
+    // cooperative verification of the candidates queued for tile t (held in s_tile); the queue must be
+    // complete (a barrier since its filter)
+    auto verify_tile = [&](const uint8_t *s_tile, int64_t t, int qa, int qc) __attribute__((always_inline)) {
+        const int64_t base = a.tile0 + t * a.tile_w; // first window start of the tile
+        const int p0 = tid * 16;
+        constexpr int NF = 16 / STRIDE;
+        const uint32_t *queue = s_queue + qa * a.qcap;
+        const uint32_t qn = s_qn[qc];
+        constexpr int NSH = 2 * BAND + 1;
+        // all keys whose tag matches at this sampled position (bucket ways, overflow list, chains);
+        // one runtime loop = ONE inlined copy of the verification code
+        auto for_each_key = [&](uint32_t tag, int pos, int dl) __attribute__((always_inline)) {
+            uint32_t fw[KL / 4];
+            apm_lds_dwords<KL / 4>(s_tile, pos, fw);
+            uint32_t fi;
+            if constexpr (KL == 16) fi = apm_fp16(apm_fp8(fw[0], fw[1]), apm_fp8(fw[2], fw[3]));
+            else fi = apm_fp8(fw[0], fw[1]);
+            const uint32_t slot = apm_table_hash<KL>(fi) >> hshift;
+            const uint16_t *tag16 = reinterpret_cast<const uint16_t *>(s_tab + slot);
+            const uint16_t *kid16p = reinterpret_cast<const uint16_t *>(s_kid + slot);
+#pragma unroll 1
+            for (int c = 0; c < 8 + a.n_ovf; ++c) {
+                uint32_t t16, kid16;
+                if (c < 8) {
+                    t16 = tag16[c];
+                    kid16 = kid16p[c];
+                } else {
+                    t16 = s_ovf[2 * (c - 8)];
+                    kid16 = s_ovf[2 * (c - 8) + 1];
+                }
+                if (t16 != tag || kid16 == 0xffffu) continue;
+                uint32_t kid = kid16 & 0x7fffu;
+                const bool more = (kid16 & 0x8000u) != 0; // heads a chain of keys with the same tag
+                for (;;) {
+                    verify_item(s_tile, base, (int)kid, pos, dl);
+                    if (!more) break;
+                    const uint32_t nxt = s_next[kid];
+                    if (!nxt) break;
+                    kid = nxt - 1u;
+                }
+            }
+        };
+        if (a.ablate & 8) { // measurement aid: skip verification
+        } else if (qn <= (uint32_t)a.qcap) { // work item = (queue entry, shift): keeps all lanes busy
+            for (uint32_t wi = tid; wi < qn * NSH; wi += APM_BLOCK) {
+                const uint32_t ent = queue[wi / NSH];
+                for_each_key(ent >> 16, (int)(ent & 0xffffu), (int)(wi % NSH) - BAND);
+            }
+        } else { // queue overflow: dense pass over every (sampled position, key, shift)
+            for (int i = 0; i < NF; ++i)
+                for (int kid = 0; kid < a.nk; ++kid)
+                    for (int dl = -BAND; dl <= BAND; ++dl) verify_item(s_tile, base, kid, p0 + i * STRIDE, dl);
+        }
+
+    };
+
+    if constexpr (DMA) {
+        for (int it = 0; t < a.ntiles; ++it, t += G) {
+            // tile t (DMA issued two iterations ago) must have landed; the DMA of tile t+G stays in flight
+            if (t + G < a.ntiles) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // every wave is past tile t-G now: its buffer takes tile t+2G
+            if (it >= 1 && t + 2 * G < a.ntiles && !(a.ablate & 2)) dma(t + 2 * G, (it + 2) % 3);
+            const uint8_t *s_tile = smem + (it % 3) * APM_FILTER_POS;
+            filter_tile(s_tile, it & 1, it & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
+            if (tid == 0) s_qn[(it + 1) & 1] = 0u; // next tile's counter (read again only after the next barrier)
+            verify_tile(s_tile, t, it & 1, it & 1);
+        }
+    } else {
+        // one iteration: filter tile t, barrier, verify it, then land the registers `r` (tile t+G) in the
+        // other buffer and refill them with tile t+3G
+        auto iteration = [&](int it, int64_t t, const uint8_t *s_tile, uint8_t *s_other, u32x4 &r0) __attribute__((always_inline)) {
+            filter_tile(s_tile, it & 1, it & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
+            if (tid == 0) s_qn[(it + 1) & 1] = 0u; // next iteration's counter (nobody reads it before barrier B)
+            verify_tile(s_tile, t, it & 1, it & 1);
+            if (t + G < a.ntiles) {
+                stash(s_other, r0);
+                if (t + 3 * G < a.ntiles && !(a.ablate & 2)) fetch(t + 3 * G, r0);
+            }
+            __syncthreads(); // B
+        };
+        for (int it = 0; t < a.ntiles; it += 2, t += 2 * G) {
+            iteration(it, t, s_tile0, s_tile1, ra0);
+            if (t + G < a.ntiles) iteration(it + 1, t + G, s_tile1, s_tile0, rb0);
+        }
     }
+    __syncthreads();
 
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
         const uint32_t c = s_cnt[i];
@@ -709,32 +866,36 @@ __global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : 6) void 
 }
 
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a) { // always >= 4352 B, which the tail workgroups need
-    return 2 * (size_t)a.tile_len + (size_t)((a.bytes_len + 15) & ~15) + (size_t)a.nb * 16 + (size_t)a.nb * 8 +
-           (size_t)((a.n_ovf + 1) & ~1) * 8 + (size_t)a.qcap * 4 + (size_t)((a.n_pats + 3) & ~3) * 4 + 16 + 16;
+    return (size_t)(a.use_dma ? 3 : 2) * (size_t)a.tile_len + (size_t)a.image_len + 2 * (size_t)a.qcap * 4 +
+           (size_t)((a.n_pats + 3) & ~3) * 4 + 16 + 16;
 }
 
-template <int BAND>
+template <int BAND, int DMA>
 static const void *apm_filter_fn_kl(int kl, int stride) {
-    if (kl == 16 && stride == 16) return (const void *)apm_filter_kernel<BAND, 16, 16>;
-    if (kl == 8 && stride == 8) return (const void *)apm_filter_kernel<BAND, 8, 8>;
-    if (kl == 8 && stride == 1) return (const void *)apm_filter_kernel<BAND, 8, 1>;
+    if (kl == 16 && stride == 16) return (const void *)apm_filter_kernel<BAND, 16, 16, DMA>;
+    if (kl == 8 && stride == 8) return (const void *)apm_filter_kernel<BAND, 8, 8, DMA>;
+    if (kl == 8 && stride == 1) return (const void *)apm_filter_kernel<BAND, 8, 1, DMA>;
     return nullptr;
 }
 
-static const void *apm_filter_fn(int band, int kl, int stride) {
-    switch (band) {
-    case 0: return apm_filter_fn_kl<0>(kl, stride);
-    case 1: return apm_filter_fn_kl<1>(kl, stride);
-    case 2: return apm_filter_fn_kl<2>(kl, stride);
-    case 3: return apm_filter_fn_kl<3>(kl, stride);
+static const void *apm_filter_fn(int band, int kl, int stride, int dma) {
+    switch (band * 2 + (dma ? 1 : 0)) {
+    case 0: return apm_filter_fn_kl<0, 0>(kl, stride);
+    case 1: return apm_filter_fn_kl<0, 1>(kl, stride);
+    case 2: return apm_filter_fn_kl<1, 0>(kl, stride);
+    case 3: return apm_filter_fn_kl<1, 1>(kl, stride);
+    case 4: return apm_filter_fn_kl<2, 0>(kl, stride);
+    case 5: return apm_filter_fn_kl<2, 1>(kl, stride);
+    case 6: return apm_filter_fn_kl<3, 0>(kl, stride);
+    case 7: return apm_filter_fn_kl<3, 1>(kl, stride);
     default: return nullptr;
     }
 }
 
 // workgroups of the filter kernel resident per CU for this LDS budget (queried once per plan)
-int apm_filter_blocks_per_cu(int band, int kl, int stride, size_t lds) {
+int apm_filter_blocks_per_cu(int band, int kl, int stride, int dma, size_t lds) {
     int per_cu = 0;
-    const void *fn = apm_filter_fn(band, kl, stride);
+    const void *fn = apm_filter_fn(band, kl, stride, dma);
     if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, APM_BLOCK, lds) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;
@@ -744,7 +905,7 @@ int apm_filter_blocks_per_cu(int band, int kl, int stride, size_t lds) {
 
 hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t s) {
     if (a.ntiles <= 0 || a.n_pats <= 0) return hipSuccess;
-    const void *fn = apm_filter_fn(a.band, a.key_len, a.stride);
+    const void *fn = apm_filter_fn(a.band, a.key_len, a.stride, a.use_dma);
     if (!fn) return hipErrorInvalidValue;
     const size_t lds = apm_filter_lds_bytes(a);
     const int64_t cap = max_blocks < 1 ? 1 : max_blocks; // persistent grid = resident workgroups

@@ -59,13 +59,17 @@ struct TiledLaunch {       // host description of one tiled scan launch
     uint8_t lut[256];
     std::vector<ApmKey> keys;         // BANDED: sub-keys
     std::vector<uint16_t> piece_off;  // BANDED: piece offsets, per pattern contiguous
-    std::vector<uint32_t> table;      // BANDED: nb x 4 tags
-    std::vector<uint16_t> table_kid;  // BANDED: nb x 4 key ids
-    std::vector<uint32_t> ovf;        // BANDED: {fp, kid} pairs
+    std::vector<uint16_t> table;      // BANDED: nb x 8 16-bit tags
+    std::vector<uint16_t> table_kid;  // BANDED: nb x 8 key ids
+    std::vector<uint32_t> ovf;        // BANDED: {tag, kid16} pairs
+    std::vector<uint32_t> kinfo;      // BANDED: per key pat | off<<12 | piece<<21
+    std::vector<uint32_t> pinfo;      // BANDED: per pattern {byte_off | m<<16, aux_off}
+    std::vector<uint8_t> image;       // BANDED: LDS image (bytes | table | kids | ovf | kinfo | pinfo)
+    int o_tab = 0, o_kid = 0, o_ovf = 0, o_kinfo = 0, o_pinfo = 0, o_next = 0, o_poff = 0;
     int key_len = 0, stride = 0;      // BANDED: (16,16), (8,8) or (8,1)
     int nb = 0, lg_nb = 0, qcap = 0;
     int a_max = 0;                    // BANDED: largest key offset
-    int blocks_per_cu = 0;            // BANDED: resident workgroups per CU (occupancy query, cached)
+    int blocks_per_cu[2] = {0, 0};    // BANDED: resident workgroups per CU (occupancy query, cached) [dma]
     int m_max = 0, m_min = 0, tile = 0;
     double cells_per_pos = 0; // sum m^2 over its patterns
 };
@@ -82,9 +86,7 @@ struct DevTiled {
     uint8_t *d_lut = nullptr;
     ApmKey *d_keys = nullptr;
     uint16_t *d_piece_off = nullptr;
-    uint32_t *d_table = nullptr;
-    uint16_t *d_table_kid = nullptr;
-    uint32_t *d_ovf = nullptr;
+    uint8_t *d_image = nullptr;
 };
 
 struct DeviceState {
@@ -214,9 +216,7 @@ void free_device_plan(DeviceState &ds) {
         if (t.d_lut) hipFree(t.d_lut);
         if (t.d_keys) hipFree(t.d_keys);
         if (t.d_piece_off) hipFree(t.d_piece_off);
-        if (t.d_table) hipFree(t.d_table);
-        if (t.d_table_kid) hipFree(t.d_table_kid);
-        if (t.d_ovf) hipFree(t.d_ovf);
+        if (t.d_image) hipFree(t.d_image);
     }
     ds.tiled.clear();
     if (ds.d_allpat) hipFree(ds.d_allpat), ds.d_allpat = nullptr;
@@ -370,19 +370,22 @@ int build_plan(apm_ctx *ctx) {
             return (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
         };
         auto fp8 = [](uint32_t lo, uint32_t hi) { return lo + (hi << 3); };
-        auto slot_hash = [](uint32_t f) { return (uint32_t)((uint64_t)(f & 0xffffffu) * 0x9E3779u) + (f >> 11); };
+        auto slot_hash = [](uint32_t f) {
+            return (uint32_t)((uint64_t)(f & 0xffffffu) * 0x9E3779u) + (uint32_t)((uint64_t)((f >> 12) & 0xffffffu) * 0x85EBCAu);
+        };
         for (size_t pos = 0; pos < idx.size();) {
             TiledLaunch L;
             L.kind = APM_KERNEL_BANDED;
             L.key_len = klen;
             L.stride = stride;
-            L.qcap = stride == 1 ? 4096 : 1024;
+            L.qcap = stride == 1 ? 1024 : 512;
             memset(L.lut, 0, sizeof L.lut);
             const int pieces = ctx->k + 1;
             for (; pos < idx.size(); ++pos) {
                 const PatternInfo &pi = ctx->pats[idx[pos]];
                 if (!L.descs.empty() && (L.bytes.size() + (size_t)pi.m > 16384 ||
-                                         L.keys.size() + (size_t)pieces * stride > 4096 || L.descs.size() >= 1024))
+                                         L.keys.size() + (size_t)pieces * stride > 4096 || L.descs.size() >= 1024 ||
+                                         L.piece_off.size() + (size_t)pieces > 60000))
                     break;
                 ApmPatDesc d{};
                 d.m = (uint32_t)pi.m;
@@ -414,45 +417,82 @@ int build_plan(apm_ctx *ctx) {
             }
             const int band = ctx->k / 2;
             const int front = band > 0 ? 16 : 0;
-            L.tile = (APM_FILTER_POS - front - L.a_max - band) & ~31;
+            L.tile = (APM_FILTER_POS - front - L.m_max - band) & ~31; // every window + its keys inside 4096 staged bytes
             while (L.bytes.size() % 16) L.bytes.push_back(0);
-            // hash table: 4-way buckets of fingerprint tags, keys with equal fingerprints chained
+            // compact per-key / per-pattern records the verify stage reads from LDS
+            for (const ApmKey &kk : L.keys)
+                L.kinfo.push_back((uint32_t)kk.pat | ((uint32_t)kk.off << 12) | ((uint32_t)kk.piece << 21));
+            for (const ApmPatDesc &dd : L.descs) {
+                L.pinfo.push_back(dd.byte_off | (dd.m << 16));
+                L.pinfo.push_back(dd.aux_off);
+            }
+            // hash table: 8-way buckets of 16-bit tags (low half of the slot hash), bucket = top bits;
+            // keys with equal tags in one bucket are chained behind a single entry
             int nb = 16, lg = 4;
-            while (nb < (int)L.keys.size() && nb < 2048) { nb *= 2; ++lg; }
+            while (nb * 2 < (int)L.keys.size() && nb < 512) { nb *= 2; ++lg; }
             for (;;) {
-                L.table.assign((size_t)nb * 4, APM_TAG_EMPTY);
-                L.table_kid.assign((size_t)nb * 4, 0);
+                L.table.assign((size_t)nb * 8, 0xffffu);
+                L.table_kid.assign((size_t)nb * 8, 0xffffu);
                 L.ovf.clear();
                 std::vector<int> fill((size_t)nb, 0);
                 for (auto &kk : L.keys) kk.next = 0;
                 for (size_t kid = 0; kid < L.keys.size(); ++kid) {
-                    const uint32_t f = L.keys[kid].fp;
-                    const uint32_t slot = slot_hash(f) >> (32 - lg);
+                    const uint32_t h = klen == 16 ? L.keys[kid].fp : slot_hash(L.keys[kid].fp);
+                    const uint32_t slot = h >> (32 - lg);
+                    const uint16_t tag = (uint16_t)(h & 0xffffu);
                     int head = -1;
+                    uint16_t *head_kid = nullptr;
                     for (int wv = 0; wv < fill[slot]; ++wv)
-                        if (L.table[slot * 4 + wv] == f) head = L.table_kid[slot * 4 + wv];
+                        if (L.table[slot * 8 + wv] == tag) {
+                            head = L.table_kid[slot * 8 + wv] & 0x7fff;
+                            head_kid = &L.table_kid[slot * 8 + wv];
+                        }
+                    uint32_t *head_ovf = nullptr;
                     if (head < 0)
                         for (size_t o = 0; o + 1 < L.ovf.size(); o += 2)
-                            if (L.ovf[o] == f) head = (int)L.ovf[o + 1];
-                    if (head >= 0) { // chain behind the existing entry with this fingerprint
+                            if (L.ovf[o] == tag && (L.ovf[o + 1] >> 16) == slot) {
+                                head = (int)(L.ovf[o + 1] & 0x7fff);
+                                head_ovf = &L.ovf[o + 1];
+                            }
+                    if (head >= 0) { // chain behind the existing entry with this tag
                         int tail = head;
                         while (L.keys[tail].next) tail = L.keys[tail].next - 1;
                         L.keys[tail].next = (uint16_t)(kid + 1);
-                    } else if (fill[slot] < 4) {
-                        L.table[slot * 4 + fill[slot]] = f;
-                        L.table_kid[slot * 4 + fill[slot]] = (uint16_t)kid;
+                        if (head_kid) *head_kid |= 0x8000u;
+                        if (head_ovf) *head_ovf |= 0x8000u;
+                    } else if (fill[slot] < 8) {
+                        L.table[slot * 8 + fill[slot]] = tag;
+                        L.table_kid[slot * 8 + fill[slot]] = (uint16_t)kid;
                         ++fill[slot];
                     } else {
-                        L.ovf.push_back(f);
-                        L.ovf.push_back((uint32_t)kid);
+                        L.ovf.push_back(tag);
+                        L.ovf.push_back((uint32_t)kid | (slot << 16));
                     }
                 }
-                if (L.ovf.size() / 2 <= 4 || nb >= 2048) break;
+                if (L.ovf.size() / 2 <= 4 || nb >= 1024) break;
                 nb *= 2;
                 ++lg;
             }
+            for (size_t o = 1; o < L.ovf.size(); o += 2) L.ovf[o] &= 0xffffu; // drop the slot annotation
             L.nb = nb;
             L.lg_nb = lg;
+            // one contiguous image, laid out exactly like its LDS copy
+            auto append = [&](const void *src, size_t bytes) {
+                const size_t at = L.image.size();
+                L.image.resize(at + ((bytes + 15) & ~(size_t)15), 0);
+                if (bytes) memcpy(L.image.data() + at, src, bytes);
+                return (int)at;
+            };
+            append(L.bytes.data(), L.bytes.size());
+            L.o_tab = append(L.table.data(), L.table.size() * 2);
+            L.o_kid = append(L.table_kid.data(), L.table_kid.size() * 2);
+            L.o_ovf = append(L.ovf.data(), L.ovf.size() * 4);
+            L.o_kinfo = append(L.kinfo.data(), L.kinfo.size() * 4);
+            L.o_pinfo = append(L.pinfo.data(), L.pinfo.size() * 4);
+            std::vector<uint16_t> nxt;
+            for (const ApmKey &kk : L.keys) nxt.push_back(kk.next);
+            L.o_next = append(nxt.data(), nxt.size() * 2);
+            L.o_poff = append(L.piece_off.data(), L.piece_off.size() * 2);
             ctx->tiled.push_back(std::move(L));
         }
     }
@@ -477,9 +517,7 @@ int build_plan(apm_ctx *ctx) {
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_lut, lut))) return rc;
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_keys, L.keys))) return rc;
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_piece_off, L.piece_off))) return rc;
-            if ((rc = upload_vec(ctx, &ds.tiled[t].d_table, L.table))) return rc;
-            if ((rc = upload_vec(ctx, &ds.tiled[t].d_table_kid, L.table_kid))) return rc;
-            if ((rc = upload_vec(ctx, &ds.tiled[t].d_ovf, L.ovf))) return rc;
+            if ((rc = upload_vec(ctx, &ds.tiled[t].d_image, L.image))) return rc;
         }
     }
     return APM_OK;
@@ -581,12 +619,15 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.front = f.band > 0 ? 16 : 0;
             f.tile0 = jb - (int64_t)((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)jb - (uintptr_t)f.front) & 15u);
             f.pats = ds.tiled[t].d_descs;
-            f.bytes = ds.tiled[t].d_bytes;
-            f.keys = ds.tiled[t].d_keys;
-            f.piece_off = ds.tiled[t].d_piece_off;
-            f.table = reinterpret_cast<const uint4 *>(ds.tiled[t].d_table);
-            f.table_kid = ds.tiled[t].d_table_kid;
-            f.ovf = ds.tiled[t].d_ovf;
+            f.image = reinterpret_cast<const uint4 *>(ds.tiled[t].d_image);
+            f.image_len = (int)L.image.size();
+            f.o_tab = L.o_tab;
+            f.o_kid = L.o_kid;
+            f.o_ovf = L.o_ovf;
+            f.o_kinfo = L.o_kinfo;
+            f.o_pinfo = L.o_pinfo;
+            f.o_next = L.o_next;
+            f.o_poff = L.o_poff;
             f.nk = (int)L.keys.size();
             f.nb = L.nb;
             f.lg_nb = L.lg_nb;
@@ -598,17 +639,21 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.n_pats = (int)L.descs.size();
             f.k = ctx->k;
             f.tile_w = L.tile;
-            f.tile_len = (std::max(APM_FILTER_POS + 32, f.front + L.tile + L.m_max + 16) + 15) & ~15;
-            f.bytes_len = (int)L.bytes.size();
+            f.tile_len = APM_FILTER_POS;
             f.ntiles = (je_l - f.tile0 + L.tile - 1) / L.tile;
-            if (!ctx->tiled[t].blocks_per_cu)
-                ctx->tiled[t].blocks_per_cu = apm_filter_blocks_per_cu(f.band, f.key_len, f.stride, apm_filter_lds_bytes(f));
+            {
+                static const int dma_env = getenv("APM_FILTER_DMA") ? atoi(getenv("APM_FILTER_DMA")) : 1;
+                f.use_dma = (dma_env && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) ? 1 : 0;
+            }
+            if (!ctx->tiled[t].blocks_per_cu[f.use_dma])
+                ctx->tiled[t].blocks_per_cu[f.use_dma] =
+                    apm_filter_blocks_per_cu(f.band, f.key_len, f.stride, f.use_dma, apm_filter_lds_bytes(f));
             if (tails_pending) {
                 f.n_tail = (int)ctx->stails.descs.size();
                 f.tail = ta;
                 tails_pending = false;
             }
-            HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * L.blocks_per_cu, ds.stream));
+            HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * L.blocks_per_cu[f.use_dma], ds.stream));
             ds.launches++;
             continue;
         }
