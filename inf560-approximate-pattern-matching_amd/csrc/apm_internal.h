@@ -122,6 +122,8 @@ hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t
 hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s);
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a);
 int apm_filter_blocks_per_cu(int band, int key_len, int stride, int dma, size_t lds);
+hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t s);
+int apm_stream_blocks_per_cu(const ApmFilterArgs &a);
 hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s);

@@ -513,17 +513,42 @@ __device__ __forceinline__ bool apm_key_equal(const uint8_t *tb, int toff, const
     return d == 0u;
 }
 
-// Banded DP (|x-y| <= BAND) with early exit over window tb[toff..toff+m) vs pattern pb[poff..poff+m).
+// where a candidate window's text bytes come from: the LDS tile (tile kernel) or global memory
+// (stream kernel; the bytes were streamed moments ago, so they sit in L2 / Infinity Cache)
+struct ApmLdsText {
+    const uint8_t *base; // 16-byte aligned LDS buffer
+    int off;             // window start inside it
+    __device__ __forceinline__ bool can16(int) const { return true; }
+    __device__ __forceinline__ void load16(uint32_t (&T)[4]) const { apm_lds_dwords<4>(base, off, T); }
+    __device__ __forceinline__ int byte(int x) const { return (int)base[off + x]; }
+};
+struct ApmGlobalText {
+    const uint8_t *text; // 16-byte aligned
+    int64_t off;         // window start (relative position)
+    int64_t limit;       // bytes readable from text (avail_pad)
+    __device__ __forceinline__ bool can16(int) const { return (off & ~(int64_t)3) + 20 <= limit; }
+    __device__ __forceinline__ void load16(uint32_t (&T)[4]) const {
+        const uint32_t *a = reinterpret_cast<const uint32_t *>(text + (off & ~(int64_t)3));
+        const uint32_t sh = (uint32_t)off & 3u;
+        uint32_t w[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) w[i] = a[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+    }
+    __device__ __forceinline__ int byte(int x) const { return (int)text[off + x]; }
+};
+
+// Banded DP (|x-y| <= BAND) with early exit over a window of m text bytes vs pattern pb[poff..poff+m).
 // Columns 1..16 run out of registers (bytes fetched as dwords up front, statically indexed); most
 // candidates die there.  Needs m >= 16 + BAND for the register phase, otherwise byte loop only.
-template <int BAND>
-__device__ __forceinline__ bool apm_banded_verify(const uint8_t *tb, int toff, const uint8_t *pb, int poff, int m,
-                                                  int k) {
-    const uint8_t *t = tb + toff, *p = pb + poff;
+template <int BAND, typename Text>
+__device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t *pb, int poff, int m, int k) {
+    const uint8_t *p = pb + poff;
     if constexpr (BAND == 0) {
         int mism = 0;
         for (int x = 0; x < m; ++x) {
-            mism += (t[x] != p[x]) ? 1 : 0;
+            mism += (tx.byte(x) != (int)p[x]) ? 1 : 0;
             if (mism > k) return false;
         }
         return true;
@@ -534,9 +559,9 @@ __device__ __forceinline__ bool apm_banded_verify(const uint8_t *tb, int toff, c
 #pragma unroll
         for (int i = 0; i < NB; ++i) e[i] = (i >= BAND) ? (i - BAND) : INF; // cell(0, d) = d
         int x0 = 1;
-        if (m >= 16 + BAND) {
+        if (m >= 16 + BAND && tx.can16(m)) {
             uint32_t T[4], P[5];
-            apm_lds_dwords<4>(tb, toff, T);
+            tx.load16(T);
             apm_lds_dwords<5>(pb, poff, P); // pattern bytes 0..19 (>= 16 + BAND - 1)
 #pragma unroll
             for (int x = 1; x <= 16; ++x) {
@@ -563,7 +588,7 @@ __device__ __forceinline__ bool apm_banded_verify(const uint8_t *tb, int toff, c
             x0 = 17;
         }
         for (int x = x0; x <= m; ++x) {
-            const int tc = (int)t[x - 1];
+            const int tc = tx.byte(x - 1);
             int up = INF; // cell(x, y-1) of the previous diagonal at this x
             int best = INF;
 #pragma unroll
@@ -702,7 +727,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
         const int jr = pos - a.front - key.off - dl; // window start relative to base
         const int64_t j = base + jr;
         if (jr < 0 || jr >= a.tile_w || j < a.jb || j >= je_p) return;
-        if (!apm_banded_verify<BAND>(s_tile, a.front + jr, s_pat, poff, m, a.k)) return;
+        if (!apm_banded_verify<BAND>(ApmLdsText{s_tile, a.front + jr}, s_pat, poff, m, a.k)) return;
         // count the window once: only from its first true (piece, shift) nominator
         for (int qq = 0; qq <= (int)key.piece; ++qq) {
             const int aq = (int)s_poff[d.aux_off + qq];
@@ -863,6 +888,237 @@ void apm_filter_kernel(ApmFilterArgs a) {
         const uint32_t c = s_cnt[i];
         if (c) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)c);
     }
+}
+
+// ---------------------------------------------------------------------------
+// STREAM form of the BANDED filter for the sampled classes (STRIDE == KL, 16 or 8).
+// A sampled fingerprint needs only the lane's own 16 bytes, so nothing is shared between lanes
+// while filtering: every WAVE is autonomous -- no LDS text tile, no workgroup barrier in the loop.
+// A wave walks 1 KiB chunks (16 bytes per lane, chunks c, c+W, c+2W, ... for W waves in flight),
+// keeps four buffer loads per lane in flight, probes the LDS hash table, and collects the rare
+// hits in a wave-private LDS queue (ballot + mbcnt, no atomics).  When the queue holds a wave's
+// worth of work it is verified on the spot: candidate windows are read back from global memory
+// (they were streamed moments ago: L2 / Infinity Cache hits), same banded DP + stateless dedup.
+// Requires a 16-byte aligned text pointer (sampling grid = address grid).
+// ---------------------------------------------------------------------------
+template <int BAND, int KL>
+__global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kernel(ApmFilterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: descriptors stay in SGPRs
+    if ((int)blockIdx.x >= a.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
+        apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
+        return;
+    }
+    constexpr int STRIDE = KL;
+    constexpr int NF = 16 / KL;
+    constexpr int NSH = 2 * BAND + 1;
+    constexpr int QW = 64 * NF + 64; // wave queue entries: flushed as soon as it holds >= 64
+    uint8_t *s_img = smem;
+    uint8_t *s_pat = s_img;
+    const uint4 *s_tab = reinterpret_cast<const uint4 *>(s_img + a.o_tab);
+    const uint4 *s_kid = reinterpret_cast<const uint4 *>(s_img + a.o_kid);
+    const uint32_t *s_ovf = reinterpret_cast<const uint32_t *>(s_img + a.o_ovf);
+    const uint32_t *s_kinfo = reinterpret_cast<const uint32_t *>(s_img + a.o_kinfo);
+    const uint2 *s_pinfo = reinterpret_cast<const uint2 *>(s_img + a.o_pinfo);
+    const uint16_t *s_next = reinterpret_cast<const uint16_t *>(s_img + a.o_next);
+    const uint16_t *s_poff = reinterpret_cast<const uint16_t *>(s_img + a.o_poff);
+    uint2 *s_queue = reinterpret_cast<uint2 *>(s_img + a.image_len) + wv * QW; // this wave's queue
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_img + a.image_len + 4 * QW * 8);
+
+    for (int i = tid; i < (a.image_len >> 4); i += APM_BLOCK) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
+    __syncthreads(); // the only workgroup barrier before the final count flush
+
+    const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
+    const int64_t W = (int64_t)a.n_main_blocks * (APM_BLOCK / 64);
+    const int64_t nch = a.ntiles; // 1 KiB chunks from relative position a.tile0 (multiple of 16)
+
+    auto load_chunk = [&](int64_t cc) __attribute__((always_inline)) {
+        const int64_t g = a.tile0 + cc * 1024;
+        const int64_t lim = cc < nch ? a.avail_pad - g : 0; // chunks past the end: zero records -> zeros, no traffic
+        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1024 ? 1024u : (uint32_t)lim);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+    };
+
+    // ---- verification of one (key, sampled position, shift) nomination against global text ----
+    auto verify_item = [&](int kid, int64_t pos, int dl) __attribute__((always_inline)) {
+        const uint32_t ki = s_kinfo[kid];
+        const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kpiece = (int)((ki >> 21) & 7u);
+        const uint2 pinf = s_pinfo[kpat];
+        const int m = (int)(pinf.x >> 16), aux = (int)pinf.y, poff = (int)(pinf.x & 0xffffu);
+        auto key_at = [&](int64_t tpos, int ppos) __attribute__((always_inline)) { // text[tpos..+KL) == pattern[ppos..+KL) ?
+            uint32_t y[KL / 4];
+            apm_lds_dwords<KL / 4>(s_pat, poff + ppos, y);
+            uint32_t dd;
+            if constexpr (KL == 16) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(a.text + tpos);
+                dd = (x.x ^ y[0]) | (x.y ^ y[1]) | (x.z ^ y[2]) | (x.w ^ y[3]);
+            } else {
+                const uint2 x = *reinterpret_cast<const uint2 *>(a.text + tpos);
+                dd = (x.x ^ y[0]) | (x.y ^ y[1]);
+            }
+            return dd == 0u;
+        };
+        if (!key_at(pos, koff)) return; // fingerprint / tag collision
+        const int64_t je_p = min(a.je, a.nrel - m + 1);
+        const int64_t j = pos - koff - dl; // candidate window start
+        if (j < a.jb || j >= je_p) return;
+        if (!apm_banded_verify<BAND>(ApmGlobalText{a.text, j, a.avail_pad}, s_pat, poff, m, a.k)) return;
+        // count the window once: only from its first true (piece, shift) nominator
+        for (int qq = 0; qq <= kpiece; ++qq) {
+            const int aq = (int)s_poff[aux + qq];
+            for (int dd = -BAND; dd <= BAND; ++dd) {
+                if (qq == kpiece && dd >= dl) break;
+                const int64_t o = j + aq + dd;                                   // piece start under shift dd
+                const int rr = (int)((STRIDE - (o & (STRIDE - 1))) & (STRIDE - 1)); // its sampled (aligned) block
+                if (o + rr >= 0 && key_at(o + rr, aq + rr)) return;
+            }
+        }
+        atomicAdd(&s_cnt[kpat], 1u);
+    };
+
+    auto flush = [&](uint32_t qcount) __attribute__((always_inline)) {
+        for (uint32_t wi = lane; wi < qcount * NSH; wi += 64) {
+            const uint2 ent = s_queue[wi / NSH];
+            const int dl = (int)(wi % NSH) - BAND;
+            const uint32_t tag = ent.y & 0xffffu;
+            const int64_t pos = (int64_t)ent.x | ((int64_t)(ent.y >> 16) << 32);
+            if (pos + KL > a.avail) continue;
+            uint32_t fi;
+            if constexpr (KL == 16) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(a.text + pos);
+                fi = apm_fp16(apm_fp8(x.x, x.y), apm_fp8(x.z, x.w));
+            } else {
+                const uint2 x = *reinterpret_cast<const uint2 *>(a.text + pos);
+                fi = apm_fp8(x.x, x.y);
+            }
+            const uint32_t slot = apm_table_hash<KL>(fi) >> hshift;
+            const uint16_t *tag16 = reinterpret_cast<const uint16_t *>(s_tab + slot);
+            const uint16_t *kid16p = reinterpret_cast<const uint16_t *>(s_kid + slot);
+#pragma unroll 1
+            for (int c = 0; c < 8 + a.n_ovf; ++c) {
+                uint32_t t16, kid16;
+                if (c < 8) {
+                    t16 = tag16[c];
+                    kid16 = kid16p[c];
+                } else {
+                    t16 = s_ovf[2 * (c - 8)];
+                    kid16 = s_ovf[2 * (c - 8) + 1];
+                }
+                if (t16 != tag || kid16 == 0xffffu) continue;
+                uint32_t kid = kid16 & 0x7fffu;
+                const bool more = (kid16 & 0x8000u) != 0;
+                for (;;) {
+                    verify_item((int)kid, pos, dl);
+                    if (!more) break;
+                    const uint32_t nxt = s_next[kid];
+                    if (!nxt) break;
+                    kid = nxt - 1u;
+                }
+            }
+        }
+    };
+
+    uint32_t qcount = 0; // wave-uniform
+    auto probe = [&](uint32_t fi, int64_t pos, bool valid) __attribute__((always_inline)) {
+        const uint32_t h = apm_table_hash<KL>(fi);
+        const uint32_t slot = h >> hshift;
+        const uint32_t tag = h & 0xffffu;
+        const uint32_t rep = tag | (tag << 16);
+        const uint4 tg = s_tab[slot];
+        const u16x2 m01 = __builtin_elementwise_min(apm_as_u16x2(tg.x ^ rep), apm_as_u16x2(tg.y ^ rep));
+        const u16x2 m23 = __builtin_elementwise_min(apm_as_u16x2(tg.z ^ rep), apm_as_u16x2(tg.w ^ rep));
+        const u16x2 mm = __builtin_elementwise_min(m01, m23);
+        bool hit = (mm.x == 0) | (mm.y == 0);
+        for (int o = 0; o < a.n_ovf; ++o) hit |= (s_ovf[2 * o] == tag);
+        hit &= valid;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+        if (mask) { // rare
+            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (hit) s_queue[idx] = make_uint2((uint32_t)pos, ((uint32_t)(pos >> 32) << 16) | tag);
+            qcount += (uint32_t)__builtin_popcountll(mask);
+        }
+    };
+    auto process = [&](const u32x4 &v, int64_t cc) __attribute__((always_inline)) {
+        const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
+        const bool valid = cc < nch && !(a.ablate & 1);
+        if constexpr (KL == 16) {
+            probe(apm_fp16(apm_fp8(v.x, v.y), apm_fp8(v.z, v.w)), pos, valid);
+        } else {
+            probe(apm_fp8(v.x, v.y), pos, valid);
+            probe(apm_fp8(v.z, v.w), pos + 8, valid);
+        }
+        if (qcount >= 64u) {
+            flush(qcount);
+            qcount = 0;
+        }
+    };
+
+    int64_t c = (int64_t)blockIdx.x * (APM_BLOCK / 64) + wv;
+    u32x4 r0 = load_chunk(c), r1 = load_chunk(c + W), r2 = load_chunk(c + 2 * W), r3 = load_chunk(c + 3 * W);
+    for (; c < nch; c += 4 * W) {
+        { const u32x4 v = r0; r0 = load_chunk(c + 4 * W); process(v, c); }
+        { const u32x4 v = r1; r1 = load_chunk(c + 5 * W); process(v, c + W); }
+        { const u32x4 v = r2; r2 = load_chunk(c + 6 * W); process(v, c + 2 * W); }
+        { const u32x4 v = r3; r3 = load_chunk(c + 7 * W); process(v, c + 3 * W); }
+    }
+    flush(qcount);
+
+    __syncthreads();
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
+        const uint32_t cnt = s_cnt[i];
+        if (cnt) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)cnt);
+    }
+}
+
+static size_t apm_stream_lds_bytes(const ApmFilterArgs &a) {
+    const size_t qw = (size_t)(64 * (16 / a.key_len) + 64);
+    size_t b = (size_t)a.image_len + 4 * qw * 8 + (size_t)((a.n_pats + 3) & ~3) * 4 + 16;
+    return b < 4608 ? 4608 : b; // the tail workgroups need 256 uint4 + 128 bytes
+}
+
+template <int BAND>
+static const void *apm_stream_fn_kl(int kl) {
+    if (kl == 16) return (const void *)apm_stream_kernel<BAND, 16>;
+    if (kl == 8) return (const void *)apm_stream_kernel<BAND, 8>;
+    return nullptr;
+}
+static const void *apm_stream_fn(int band, int kl) {
+    switch (band) {
+    case 0: return apm_stream_fn_kl<0>(kl);
+    case 1: return apm_stream_fn_kl<1>(kl);
+    case 2: return apm_stream_fn_kl<2>(kl);
+    case 3: return apm_stream_fn_kl<3>(kl);
+    default: return nullptr;
+    }
+}
+
+int apm_stream_blocks_per_cu(const ApmFilterArgs &a) {
+    int per_cu = 0;
+    const void *fn = apm_stream_fn(a.band, a.key_len);
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, APM_BLOCK, apm_stream_lds_bytes(a)) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    return per_cu > 8 ? 8 : per_cu;
+}
+
+// a.tile0 = first scanned relative position (multiple of 16), a.ntiles = number of 1 KiB chunks
+hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t s) {
+    if (a.ntiles <= 0 || a.n_pats <= 0) return hipSuccess;
+    const void *fn = apm_stream_fn(a.band, a.key_len);
+    if (!fn) return hipErrorInvalidValue;
+    const int64_t want = (a.ntiles + 3) / 4;
+    const int64_t cap = max_blocks < 1 ? 1 : max_blocks;
+    const int64_t nb = want < cap ? want : cap;
+    ApmFilterArgs args = a;
+    args.n_main_blocks = (int)nb;
+    if (const char *e = getenv("APM_FILTER_ABLATE")) args.ablate = atoi(e); // measurement aid, results invalid
+    void *kargs[] = {&args};
+    return hipLaunchKernel(fn, dim3((unsigned)(nb + a.n_tail)), dim3(APM_BLOCK), kargs, apm_stream_lds_bytes(a), s);
 }
 
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a) { // always >= 4352 B, which the tail workgroups need

@@ -69,7 +69,7 @@ struct TiledLaunch {       // host description of one tiled scan launch
     int key_len = 0, stride = 0;      // BANDED: (16,16), (8,8) or (8,1)
     int nb = 0, lg_nb = 0, qcap = 0;
     int a_max = 0;                    // BANDED: largest key offset
-    int blocks_per_cu[2] = {0, 0};    // BANDED: resident workgroups per CU (occupancy query, cached) [dma]
+    int blocks_per_cu[3] = {0, 0, 0}; // BANDED: resident workgroups per CU (occupancy query, cached) [tile, tile+dma, stream]
     int m_max = 0, m_min = 0, tile = 0;
     double cells_per_pos = 0; // sum m^2 over its patterns
 };
@@ -644,6 +644,23 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             {
                 static const int dma_env = getenv("APM_FILTER_DMA") ? atoi(getenv("APM_FILTER_DMA")) : 1;
                 f.use_dma = (dma_env && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) ? 1 : 0;
+            }
+            static const int stream_env = getenv("APM_FILTER_STREAM") ? atoi(getenv("APM_FILTER_STREAM")) : 1;
+            if (stream_env && L.stride > 1 && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
+                // sampled classes: wave-autonomous streaming kernel over 1 KiB chunks
+                const int64_t p_lo = std::max<int64_t>(0, jb - f.band) & ~(int64_t)15;
+                const int64_t p_hi = std::min<int64_t>(avail, je_l + L.m_max + f.band);
+                f.tile0 = p_lo;
+                f.ntiles = p_hi > p_lo ? (p_hi - p_lo + 1023) / 1024 : 0;
+                if (!ctx->tiled[t].blocks_per_cu[2]) ctx->tiled[t].blocks_per_cu[2] = apm_stream_blocks_per_cu(f);
+                if (tails_pending) {
+                    f.n_tail = (int)ctx->stails.descs.size();
+                    f.tail = ta;
+                    tails_pending = false;
+                }
+                HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
+                ds.launches++;
+                continue;
             }
             if (!ctx->tiled[t].blocks_per_cu[f.use_dma])
                 ctx->tiled[t].blocks_per_cu[f.use_dma] =
