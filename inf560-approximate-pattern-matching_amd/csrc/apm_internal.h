@@ -14,7 +14,7 @@
 #define APM_WAVEFRONT_MAX_M 256
 #define APM_LDS_TABLE_BUDGET (40 * 1024)
 #define APM_BANDED_MAX_M 256
-#define APM_BANDED_MIN_PIECE 8
+#define APM_BANDED_MIN_PIECE 4
 #define APM_BANDED_MAX_K 7
 #define APM_BANDED_MAX_PATS 64
 
@@ -103,7 +103,7 @@ struct ApmFilterArgs {
     int n_pats, nk;
     int nb, lg_nb, n_ovf;  /* hash table geometry */
     int qcap;              /* candidate queue entries */
-    int key_len, stride;   /* (16,16), (8,8) or (8,1) */
+    int key_len, stride;   /* (16,16), (8,8), (8,1), (6,1) or (4,1) */
     int k, band;           /* band = k/2 */
     int tile_w;            /* window starts per workgroup tile (multiple of 32) */
     int front;             /* bytes staged in front of the first window (0 or 16) */

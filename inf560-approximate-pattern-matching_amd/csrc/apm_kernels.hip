@@ -502,14 +502,25 @@ __device__ __forceinline__ void apm_lds_dwords(const uint8_t *base, int off, uin
     for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
 }
 
+// mask of the key bytes living in the second dword of an (up to) 8-byte key
+template <int KL>
+__device__ __forceinline__ constexpr uint32_t apm_hi_mask() {
+    return KL >= 8 ? 0xffffffffu : (KL <= 4 ? 0u : ((1u << (8 * (KL - 4))) - 1u));
+}
+
 template <int KL>
 __device__ __forceinline__ bool apm_key_equal(const uint8_t *tb, int toff, const uint8_t *pb, int poff) {
-    uint32_t x[KL / 4], y[KL / 4];
-    apm_lds_dwords<KL / 4>(tb, toff, x);
-    apm_lds_dwords<KL / 4>(pb, poff, y);
+    constexpr int ND = (KL + 3) / 4;
+    uint32_t x[ND], y[ND];
+    apm_lds_dwords<ND>(tb, toff, x);
+    apm_lds_dwords<ND>(pb, poff, y);
     uint32_t d = 0;
 #pragma unroll
-    for (int i = 0; i < KL / 4; ++i) d |= x[i] ^ y[i];
+    for (int i = 0; i < ND; ++i) {
+        uint32_t t = x[i] ^ y[i];
+        if (i == ND - 1 && (KL & 3)) t &= (1u << (8 * (KL & 3))) - 1u;
+        d |= t;
+    }
     return d == 0u;
 }
 
@@ -541,7 +552,7 @@ struct ApmGlobalText {
 
 // Banded DP (|x-y| <= BAND) with early exit over a window of m text bytes vs pattern pb[poff..poff+m).
 // Columns 1..16 run out of registers (bytes fetched as dwords up front, statically indexed); most
-// candidates die there.  Needs m >= 16 + BAND for the register phase, otherwise byte loop only.
+// candidates die there.  Needs m >= 16 for the register phase, otherwise byte loop only.
 template <int BAND, typename Text>
 __device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t *pb, int poff, int m, int k) {
     const uint8_t *p = pb + poff;
@@ -559,7 +570,7 @@ __device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t 
 #pragma unroll
         for (int i = 0; i < NB; ++i) e[i] = (i >= BAND) ? (i - BAND) : INF; // cell(0, d) = d
         int x0 = 1;
-        if (m >= 16 + BAND && tx.can16(m)) {
+        if (m >= 16 && tx.can16(m)) {
             uint32_t T[4], P[5];
             tx.load16(T);
             apm_lds_dwords<5>(pb, poff, P); // pattern bytes 0..19 (>= 16 + BAND - 1)
@@ -573,6 +584,8 @@ __device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t 
                     int nv;
                     if (y < 1) {
                         nv = (y == 0) ? x : INF;
+                    } else if (y > 16 && y > m) { // only reachable for 16 <= m < 16 + BAND
+                        nv = INF;
                     } else {
                         const int pc = (int)((P[(y - 1) >> 2] >> (8 * ((y - 1) & 3))) & 0xffu);
                         const int diag = e[i] + ((pc != tc) ? 1 : 0);
@@ -760,15 +773,19 @@ void apm_filter_kernel(ApmFilterArgs a) {
             } else if constexpr (STRIDE == 8) {
                 f[0] = apm_fp8(va.x, va.y);
                 f[1] = apm_fp8(va.z, va.w);
-            } else { // every position: KL = 8
+            } else { // every position: KL = 8, 6 or 4 key bytes
                 const uint2 vb = *reinterpret_cast<const uint2 *>(s_tile + p0 + 16);
                 const uint32_t w[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
-                uint32_t k0[20];
+                constexpr int NK0 = KL > 4 ? 20 : 16;
+                uint32_t k0[NK0];
 #pragma unroll
-                for (int i = 0; i < 20; ++i)
+                for (int i = 0; i < NK0; ++i)
                     k0[i] = (i & 3) ? __builtin_amdgcn_alignbyte(w[i / 4 + 1], w[i / 4], (uint32_t)(i & 3)) : w[i / 4];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) f[i] = apm_fp8(k0[i], k0[i + 4]);
+                for (int i = 0; i < 16; ++i) {
+                    if constexpr (KL > 4) f[i] = apm_fp8(k0[i], k0[i + 4] & apm_hi_mask<KL>());
+                    else f[i] = k0[i];
+                }
             }
         }
 
@@ -806,14 +823,19 @@ void apm_filter_kernel(ApmFilterArgs a) {
         // all keys whose tag matches at this sampled position (bucket ways, overflow list, chains);
         // one runtime loop = ONE inlined copy of the verification code
         auto for_each_key = [&](uint32_t tag, int pos, int dl) __attribute__((always_inline)) {
-            uint32_t fw[KL / 4];
-            apm_lds_dwords<KL / 4>(s_tile, pos, fw);
+            uint32_t fw[(KL + 3) / 4];
+            apm_lds_dwords<(KL + 3) / 4>(s_tile, pos, fw);
             uint32_t fi;
             if constexpr (KL == 16) fi = apm_fp16(apm_fp8(fw[0], fw[1]), apm_fp8(fw[2], fw[3]));
-            else fi = apm_fp8(fw[0], fw[1]);
+            else if constexpr (KL > 4) fi = apm_fp8(fw[0], fw[1] & apm_hi_mask<KL>());
+            else fi = fw[0];
             const uint32_t slot = apm_table_hash<KL>(fi) >> hshift;
             const uint16_t *tag16 = reinterpret_cast<const uint16_t *>(s_tab + slot);
             const uint16_t *kid16p = reinterpret_cast<const uint16_t *>(s_kid + slot);
+            // Find this lane's matching way first (cheap scan), THEN verify: all lanes of the wave run the
+            // banded DP together instead of once per way index with 1/8 of the lanes active.
+            uint32_t first = 0xffffffffu;
+            int n_match = 0;
 #pragma unroll 1
             for (int c = 0; c < 8 + a.n_ovf; ++c) {
                 uint32_t t16, kid16;
@@ -825,14 +847,43 @@ void apm_filter_kernel(ApmFilterArgs a) {
                     kid16 = s_ovf[2 * (c - 8) + 1];
                 }
                 if (t16 != tag || kid16 == 0xffffu) continue;
-                uint32_t kid = kid16 & 0x7fffu;
-                const bool more = (kid16 & 0x8000u) != 0; // heads a chain of keys with the same tag
+                if (n_match == 0) first = kid16;
+                ++n_match;
+            }
+            if (n_match > 0) {
+                uint32_t kid = first & 0x7fffu;
+                const bool more = (first & 0x8000u) != 0; // heads a chain of keys with the same tag
                 for (;;) {
                     verify_item(s_tile, base, (int)kid, pos, dl);
                     if (!more) break;
                     const uint32_t nxt = s_next[kid];
                     if (!nxt) break;
                     kid = nxt - 1u;
+                }
+            }
+            if (n_match > 1) { // several ways carry this tag (rare): walk the remaining ones
+                int seen = 0;
+#pragma unroll 1
+                for (int c = 0; c < 8 + a.n_ovf; ++c) {
+                    uint32_t t16, kid16;
+                    if (c < 8) {
+                        t16 = tag16[c];
+                        kid16 = kid16p[c];
+                    } else {
+                        t16 = s_ovf[2 * (c - 8)];
+                        kid16 = s_ovf[2 * (c - 8) + 1];
+                    }
+                    if (t16 != tag || kid16 == 0xffffu) continue;
+                    if (seen++ == 0) continue;
+                    uint32_t kid = kid16 & 0x7fffu;
+                    const bool more = (kid16 & 0x8000u) != 0;
+                    for (;;) {
+                        verify_item(s_tile, base, (int)kid, pos, dl);
+                        if (!more) break;
+                        const uint32_t nxt = s_next[kid];
+                        if (!nxt) break;
+                        kid = nxt - 1u;
+                    }
                 }
             }
         };
@@ -998,6 +1049,8 @@ __global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kerne
             const uint32_t slot = apm_table_hash<KL>(fi) >> hshift;
             const uint16_t *tag16 = reinterpret_cast<const uint16_t *>(s_tab + slot);
             const uint16_t *kid16p = reinterpret_cast<const uint16_t *>(s_kid + slot);
+            uint32_t first = 0xffffffffu; // this lane's matching way (cheap scan), verified with the whole wave
+            int n_match = 0;
 #pragma unroll 1
             for (int c = 0; c < 8 + a.n_ovf; ++c) {
                 uint32_t t16, kid16;
@@ -1009,14 +1062,43 @@ __global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kerne
                     kid16 = s_ovf[2 * (c - 8) + 1];
                 }
                 if (t16 != tag || kid16 == 0xffffu) continue;
-                uint32_t kid = kid16 & 0x7fffu;
-                const bool more = (kid16 & 0x8000u) != 0;
+                if (n_match == 0) first = kid16;
+                ++n_match;
+            }
+            if (n_match > 0) {
+                uint32_t kid = first & 0x7fffu;
+                const bool more = (first & 0x8000u) != 0;
                 for (;;) {
                     verify_item((int)kid, pos, dl);
                     if (!more) break;
                     const uint32_t nxt = s_next[kid];
                     if (!nxt) break;
                     kid = nxt - 1u;
+                }
+            }
+            if (n_match > 1) { // several ways carry this tag (rare)
+                int seen = 0;
+#pragma unroll 1
+                for (int c = 0; c < 8 + a.n_ovf; ++c) {
+                    uint32_t t16, kid16;
+                    if (c < 8) {
+                        t16 = tag16[c];
+                        kid16 = kid16p[c];
+                    } else {
+                        t16 = s_ovf[2 * (c - 8)];
+                        kid16 = s_ovf[2 * (c - 8) + 1];
+                    }
+                    if (t16 != tag || kid16 == 0xffffu) continue;
+                    if (seen++ == 0) continue;
+                    uint32_t kid = kid16 & 0x7fffu;
+                    const bool more = (kid16 & 0x8000u) != 0;
+                    for (;;) {
+                        verify_item((int)kid, pos, dl);
+                        if (!more) break;
+                        const uint32_t nxt = s_next[kid];
+                        if (!nxt) break;
+                        kid = nxt - 1u;
+                    }
                 }
             }
         }
@@ -1131,6 +1213,8 @@ static const void *apm_filter_fn_kl(int kl, int stride) {
     if (kl == 16 && stride == 16) return (const void *)apm_filter_kernel<BAND, 16, 16, DMA>;
     if (kl == 8 && stride == 8) return (const void *)apm_filter_kernel<BAND, 8, 8, DMA>;
     if (kl == 8 && stride == 1) return (const void *)apm_filter_kernel<BAND, 8, 1, DMA>;
+    if (kl == 6 && stride == 1) return (const void *)apm_filter_kernel<BAND, 6, 1, DMA>;
+    if (kl == 4 && stride == 1) return (const void *)apm_filter_kernel<BAND, 4, 1, DMA>;
     return nullptr;
 }
 

@@ -199,7 +199,7 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
         return APM_KERNEL_BITPAR;
     case APM_KERNEL_BANDED:
         if (m > APM_BANDED_MAX_M || k > APM_BANDED_MAX_K || m / (k + 1) < APM_BANDED_MIN_PIECE) {
-            *why = "BANDED kernel needs m <= 256, k <= 7 and m/(k+1) >= 8 (pigeonhole keys of 8 bytes)";
+            *why = "BANDED kernel needs m <= 256, k <= 7 and m/(k+1) >= 4 (pigeonhole keys of >= 4 bytes)";
             return -100;
         }
         return APM_KERNEL_BANDED;
@@ -356,12 +356,13 @@ int build_plan(apm_ctx *ctx) {
     }
 
     // ---- BANDED launches: patterns grouped by (key length, sampling stride); k+1 pigeonhole pieces each ----
-    for (int cls = 0; cls < 3; ++cls) {
-        const int klen = cls == 0 ? 16 : 8;
-        const int stride = cls == 0 ? 16 : (cls == 1 ? 8 : 1);
+    for (int cls = 0; cls < 5; ++cls) {
+        static const int kl_of[5] = {16, 8, 8, 6, 4}, st_of[5] = {16, 8, 1, 1, 1};
+        const int klen = kl_of[cls];
+        const int stride = st_of[cls];
         auto class_of = [&](int m) {
             const int piece = m / (ctx->k + 1);
-            return piece >= 31 ? 0 : (piece >= 15 ? 1 : 2);
+            return piece >= 31 ? 0 : (piece >= 15 ? 1 : (piece >= 8 ? 2 : (piece >= 6 ? 3 : 4)));
         };
         std::vector<int> idx;
         for (int i = 0; i < P; ++i)
@@ -398,14 +399,16 @@ int build_plan(apm_ctx *ctx) {
                     const int aq = (int)((int64_t)q * pi.m / pieces);
                     L.piece_off.push_back((uint16_t)aq);
                     for (int r = 0; r < stride; ++r) {
-                        const unsigned char *b = (const unsigned char *)pi.bytes.data() + aq + r;
+                        unsigned char b[16] = {0}; // key bytes, zero padded past the end of the pattern
+                        for (int z = 0; z < klen && aq + r + z < pi.m; ++z) b[z] = (unsigned char)pi.bytes[aq + r + z];
                         ApmKey key{};
                         key.pat = (uint16_t)L.descs.size();
                         key.off = (uint16_t)(aq + r);
                         key.piece = (uint16_t)q;
                         key.next = 0;
-                        if (klen == 8) key.fp = fp8(dword(b), dword(b + 4));
-                        else key.fp = fp8(dword(b), dword(b + 4)) + (fp8(dword(b + 8), dword(b + 12)) & 0xffffffu) * 0x9E3779u;
+                        if (klen == 16) key.fp = fp8(dword(b), dword(b + 4)) + (fp8(dword(b + 8), dword(b + 12)) & 0xffffffu) * 0x9E3779u;
+                        else if (klen == 4) key.fp = dword(b);
+                        else key.fp = fp8(dword(b), dword(b + 4)); // bytes past klen are zero (masked on the device)
                         L.keys.push_back(key);
                         L.a_max = std::max(L.a_max, aq + r);
                     }

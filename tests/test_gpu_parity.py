@@ -22,7 +22,7 @@ def _supported(variant, m, k):
     if m > MAX_M[variant]:
         return False
     if variant == "banded":
-        return k <= 7 and m // (k + 1) >= 8
+        return k <= 7 and m // (k + 1) >= 4
     return True
 
 CASES = H.golden()["cases"]
