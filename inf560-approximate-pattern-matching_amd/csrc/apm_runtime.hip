@@ -782,7 +782,8 @@ int reduce_counts(apm_ctx *ctx, uint64_t *counts) {
     const auto t0 = clk::now();
     const size_t G = ctx->devs.size();
     bool done = false;
-    if (G > 1 && !getenv("APM_NO_RCCL")) {
+    // APM_FORCE_RCCL=1 runs the collective even on one device (test hook for the RCCL path)
+    if ((G > 1 || getenv("APM_FORCE_RCCL")) && !getenv("APM_NO_RCCL")) {
         if (load_rccl(ctx) == APM_OK) {
             // one ncclAllReduce(sum, uint64 x P) per device, grouped (RCCL over xGMI);
             // replaces the MPI_Send/Recv + manual sum of database_over_ranks.c:174-195

@@ -381,3 +381,61 @@ def test_custom_unaligned_shard_cuts(ctx, apm):
         raw = ctx.device_download(d_counts, 8 * len(pats))
         ctx.device_free(d_counts)
         assert [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(len(pats))] == c["counts"], variant
+
+
+# ---------------------------------------------------------------- scale: 64-bit offsets, big files, RCCL
+def test_text_beyond_4gib_on_device(ctx, apm):
+    """5 GiB synthetic text on one device (the reference's int / single read() stop at 2 GiB):
+    planted exact copies + truncated-tail matches, BASELINE cfg2's pattern set."""
+    wl = H.workloads()
+    c = wl.CONFIGS["cfg2"]
+    n, k, seed = 5 << 30, c["k"], wl.seed_of(c["cid"])
+    pats, planted = wl.make_patterns(n, c["lens"], k, seed)
+    ctx.set_kernel("auto")
+    ctx.set_patterns(pats, k)
+    got = ctx.count_synthetic(n, seed)
+    assert got == wl.expected_counts_k0(n, pats, planted, seed)
+    t = ctx.timing()
+    assert t["text_bytes"] >= n
+
+
+def test_cli_file_larger_than_2gib(tmp_path_factory, apm):
+    """apm_parallel on a 2.25 GiB file (64-bit chunked ingest) == device-resident scan of the same bytes"""
+    if not os.path.exists(CLI):
+        pytest.skip("host/apm_parallel not built")
+    wl = H.workloads()
+    n, k, seed = (9 << 28) + 12345, 1, wl.seed_of(4)
+    lens = [40, 64, 100]
+    pats, planted = wl.make_patterns(n, lens, k, seed)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path_factory.mktemp("big"))
+    path = os.path.join(base, "apm_big_%d.fa" % os.getpid())
+    try:
+        with open(path, "wb") as f:
+            step = 1 << 26
+            for off in range(0, n, step):
+                f.write(apm.synth_fill_host(off, min(step, n - off), seed))
+        with apm.ApmContext(device=0) as c2:
+            c2.set_patterns(pats, k)
+            want = c2.count_synthetic(n, seed)
+            assert all(w >= 1 for w, (o, d) in zip(want, planted) if d <= k)
+            assert c2.count_file(path) == want
+        r = _cli([str(k), path] + [p.decode() for p in pats])
+        assert r.returncode == 0, r.stderr
+        got = [int(l.rsplit(": ", 1)[1]) for l in r.stdout.decode().splitlines() if l.startswith("Number of matches")]
+        assert got == want
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+def test_rccl_allreduce_path_single_device(apm):
+    """single-process mode: counts go through ncclAllReduce (dlopen'ed librccl) when APM_FORCE_RCCL=1"""
+    c = next(c for c in CASES if c["name"] == "chrY_k3")
+    env = dict(os.environ, APM_FORCE_RCCL="1")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import helpers as H; apm = H.pkg();"
+            "c = next(c for c in H.golden()['cases'] if c['name'] == 'chrY_k3');"
+            "ctx = apm.ApmContext(n_devices=1); ctx.set_patterns(c['patterns'], c['k']);"
+            "print(ctx.count_buffer(H.case_text(c)))") % (H.ROOT, os.path.join(H.ROOT, "tests"))
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode().strip().splitlines()[-1] == str(c["counts"])
