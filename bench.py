@@ -138,14 +138,15 @@ def main():
     ob, oe, lo, hi = sharding.rank_shard(n_total, k, m_max, rank, world)
     text = torch.empty(hi - lo + 16, dtype=torch.uint8, device=dev)
     ctx.synth_fill_device(text.data_ptr(), lo, hi - lo, seed)   # inputs resident in HBM
-    # two count vectors: the all-reduce of step i (RCCL's own stream) overlaps the scan of step i+1
-    ring = [torch.zeros(P, dtype=torch.int64, device=dev) for _ in range(2)]
-    pending = [None, None]
+    # ring of count vectors: the all-reduce of step i (RCCL's own stream) overlaps the scans of the next steps
+    RING = 4
+    ring = [torch.zeros(P, dtype=torch.int64, device=dev) for _ in range(RING)]
+    pending = [None] * RING
     counts = ring[0]
     torch.cuda.synchronize()
 
     def step(i):
-        b = i & 1
+        b = i % RING
         if pending[b] is not None:
             pending[b].wait()                                   # buffer free again (stream-level wait)
             pending[b] = None
@@ -162,7 +163,7 @@ def main():
         return c
 
     def drain():
-        for b in (0, 1):
+        for b in range(RING):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
