@@ -439,3 +439,65 @@ def test_rccl_allreduce_path_single_device(apm):
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert r.stdout.decode().strip().splitlines()[-1] == str(c["counts"])
+
+
+# ---------------------------------------------------------------- filter corner cases (chains, overflow, big k)
+@pytest.mark.parametrize("variant", ["auto", "banded"])
+def test_repeated_pieces_and_identical_patterns(ctx, apm, variant):
+    """patterns whose pigeonhole pieces are equal (fingerprint chains in the hash table), identical
+    patterns (every key duplicated), and periodic texts where every piece matches at every shift:
+    the stateless dedup must still count each window exactly once"""
+    rnd = random.Random(77)
+    unit = b"ACGTTGCA"
+    texts = [unit * 600, b"".join(rnd.choice([unit, b"ACGTTGCC", b"TTTTTTTT"]) for _ in range(700))]
+    for text in texts:
+        for k in (0, 1, 2, 3, 5, 7):
+            pats = [unit * 4, unit * 4, unit * 8, (unit * 8)[3:35], unit * 16, unit * 32]
+            pats = [p for p in pats if _supported(variant, len(p), k)]
+            want = H.oracle_counts(text, pats, k, banded=True)
+            assert _run(ctx, apm, variant, pats, k, text) == want, (k, [len(p) for p in pats])
+
+
+def test_many_keys_one_launch_and_split_launches(ctx, apm):
+    """> 4096 sub-keys / > 16 KiB of pattern bytes force several BANDED launches and full hash buckets"""
+    rnd = random.Random(2024)
+    text = bytes(rnd.choice(b"ACGT") for _ in range(30000))
+    pats = []
+    for i in range(700):
+        m = rnd.choice([32, 40, 64, 100])
+        o = rnd.randrange(0, len(text) - m)
+        p = bytearray(text[o:o + m])
+        if i % 3 == 0:
+            p[rnd.randrange(m)] = rnd.choice(b"ACGT")
+        pats.append(bytes(p))
+    for k in (1, 3):
+        want = H.oracle_counts(text, pats, k, banded=True)
+        assert _run(ctx, apm, "auto", pats, k, text) == want
+        assert sum(want) > 500
+
+
+@pytest.mark.parametrize("k", [4, 6, 7])
+def test_wide_bands(ctx, apm, k):
+    """band half-width 2 and 3 (k up to 7), pattern lengths up to 256, indels near the window ends"""
+    rnd = random.Random(100 + k)
+    text = bytearray(rnd.choice(b"ACGT") for _ in range(20000))
+    pats = []
+    for m in (64, 100, 128, 200, 256):
+        o = rnd.randrange(100, len(text) - m - 100)
+        p = bytearray(text[o:o + m])
+        for _e in range(k):
+            r, pos = rnd.random(), rnd.randrange(len(p))
+            if r < 0.4:
+                p[pos] = rnd.choice(b"ACGT")
+            elif r < 0.7:
+                del p[pos]
+                p.append(rnd.choice(b"ACGT"))
+            else:
+                p.insert(pos, rnd.choice(b"ACGT"))
+                p.pop()
+        pats.append(bytes(p))
+    text = bytes(text)
+    want = H.oracle_counts(text, pats, k, banded=True)
+    assert sum(want) >= 3
+    for variant in ("auto", "banded", "wavefront"):
+        assert _run(ctx, apm, variant, pats, k, text) == want, variant
