@@ -54,7 +54,9 @@ def cpu_baseline(apm, wl, pats, k, seed, gpu_slice_counts_fn):
     sample (first 1 MiB of the same synthetic text, all patterns): kind "reference" =
     oracle/_ref/apm_sequential (the reference's own sources compiled in the build
     container), else kind "port" = oracle/liboracle.so, 1 thread."""
-    sample = 1 << 20
+    # ~8e9 DP cells (10-15 s on one core): 1 MiB for cfg2, proportionally less for heavier pattern sets
+    per_pos = sum(len(p) ** 2 for p in pats)
+    sample = max(4096, min(1 << 20, int(8.6e9 / per_pos) & ~4095))
     m_max = max(len(p) for p in pats)
     text = apm.synth_fill_host(0, sample + m_max - 1, seed)
     cells = float(sample) * sum(len(p) ** 2 for p in pats)
@@ -74,7 +76,7 @@ def cpu_baseline(apm, wl, pats, k, seed, gpu_slice_counts_fn):
                 n_pos = max(0, sample - k)
                 out = dict(value=n_pos * sum(len(p) ** 2 for p in pats) / secs, unit="cells/s", cores=1,
                            kind="reference", seconds=secs,
-                           sample="first 1 MiB of the bench text (as a file), all %d patterns, k=%d, oracle/_ref/apm_sequential" % (len(pats), k))
+                           sample="first %d bytes of the bench text (as a file), all %d patterns, k=%d, oracle/_ref/apm_sequential" % (sample, len(pats), k))
         finally:
             os.unlink(path)
     import helpers as H                       # the oracle = checker (allowed here: cpu_baseline leg)
@@ -84,7 +86,7 @@ def cpu_baseline(apm, wl, pats, k, seed, gpu_slice_counts_fn):
             H.oracle().oracle_count_range(text, len(text), p, len(p), k, 0, sample)
         secs = time.time() - t0
         out = dict(value=cells / secs, unit="cells/s", cores=1, kind="port", seconds=secs,
-                   sample="first 1 MiB of the bench text, all %d patterns, k=%d, oracle/liboracle.so literal DP" % (len(pats), k))
+                   sample="first %d bytes of the bench text, all %d patterns, k=%d, oracle/liboracle.so literal DP" % (sample, len(pats), k))
     # checker: GPU counts on the same slice must equal the oracle's
     want = H.oracle_counts(text, pats, k, banded=True, j_end=sample)
     got = gpu_slice_counts_fn(text, sample)

@@ -189,6 +189,16 @@ hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s) {
 // ramp-down garbage never flows back up.  The last lane of a stream finishes
 // cell(m,m) exactly at the last step, m + Lm - 2.
 // ---------------------------------------------------------------------------
+// packed 16-bit lanes: every register holds the same DP cell of TWO adjacent windows (low / high
+// half), so one v_pk_add_u16 / v_pk_min_u16 advances two cells (distances <= 257 fit 16 bits)
+typedef unsigned short wf_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t wf_pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(wf_u16x2, a) + __builtin_bit_cast(wf_u16x2, b));
+}
+__device__ __forceinline__ uint32_t wf_pk_min(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(wf_u16x2, a), __builtin_bit_cast(wf_u16x2, b)));
+}
+
 template <int R>
 __device__ __forceinline__ uint32_t wf_scan(const uint8_t *s_tile, const uint8_t *s_pat, int m, int k,
                                             int64_t base, int64_t jb, int64_t je_p, int tile, int wave, int lane) {
@@ -198,56 +208,62 @@ __device__ __forceinline__ uint32_t wf_scan(const uint8_t *s_tile, const uint8_t
     const int y0 = lane - sig * Lm;
     const bool live = sig < S;
     const int r0 = y0 * R;
-    int pch[R];
+    constexpr uint32_t ONE2 = 0x00010001u;
+    uint32_t pch2[R]; // pattern byte of row r0+i in both halves (rows past m: never equal to a text byte)
 #pragma unroll
-    for (int i = 0; i < R; ++i) pch[i] = (r0 + i < m) ? (int)s_pat[r0 + i] : (0x100 + i);
+    for (int i = 0; i < R; ++i) pch2[i] = ((r0 + i < m) ? (uint32_t)s_pat[r0 + i] : (uint32_t)(0x100 + i)) * ONE2;
     const bool row0 = (y0 == 0);
     const bool is_res = live && (y0 == Lm - 1);
     const int ires = (m - 1) - (Lm - 1) * R;
     const int nsteps = m + Lm - 1;
+    const uint32_t xbase2 = (uint32_t)(2 - y0) * ONE2; // + s*ONE2 = cell(x, 0) + 1 = x + 1 in both halves
+    uint32_t one2 = ONE2;
+    asm volatile("" : "+v"(one2)); // opaque: keeps min(x, 1) a single v_pk_min_u16 (LLVM would expand it to compares)
     uint32_t cnt = 0;
 
-    for (int g0 = wave * S; g0 < tile; g0 += (APM_BLOCK / 64) * S) {
-        const int joff = live ? g0 + sig : g0; // idle lanes shadow stream 0, never counted
-        int cp1[R];
+    for (int g0 = wave * 2 * S; g0 < tile; g0 += (APM_BLOCK / 64) * 2 * S) {
+        const int joff = live ? g0 + 2 * sig : g0; // window A = joff (low half), window B = joff + 1 (high half)
+        uint32_t cp[R];                            // cell(x-1, r) + 1, packed
 #pragma unroll
-        for (int i = 0; i < R; ++i) cp1[i] = r0 + i + 2; // cell(0, r0+i+1) + 1
-        int upprev = r0 + 1;                             // cell(0, r0) + 1
+        for (int i = 0; i < R; ++i) cp[i] = (uint32_t)(r0 + i + 2) * ONE2; // cell(0, r0+i+1) + 1
+        uint32_t upprev = (uint32_t)(r0 + 1) * ONE2;                        // cell(0, r0) + 1
         const int cidx = joff - y0;
 
-        auto step = [&](int s, int recv) {
-            const int x = s - y0 + 1;
-            int up = row0 ? x + 1 : recv; // cell(x, r0) + 1
-            int dg = row0 ? x : upprev;   // cell(x-1, r0) + 1
+        auto step = [&](int s, uint32_t recv) __attribute__((always_inline)) {
+            uint32_t up = row0 ? xbase2 + (uint32_t)s * ONE2 : recv; // cell(x, r0) + 1
+            uint32_t dg = upprev;                                    // cell(x-1, r0) + 1
             upprev = up;
-            const int tch = (int)s_tile[cidx + s];
+            const uint32_t tch2 = (uint32_t)s_tile[cidx + s] | ((uint32_t)s_tile[cidx + s + 1] << 16);
 #pragma unroll
             for (int i = 0; i < R; ++i) {
-                const int left = cp1[i];                  // cell(x-1, r) + 1
-                const int t = dg - (tch == pch[i] ? 1 : 0); // cell(x-1, r-1) + neq
-                const int v = apm_min3(left, up, t);      // cell(x, r)
+                const uint32_t left = cp[i];
+                const uint32_t neq = wf_pk_min(tch2 ^ pch2[i], one2);            // 0/1 per half
+                const uint32_t v = wf_pk_min(wf_pk_add(wf_pk_min(left, up), ONE2), // min(left, up) + 1
+                                             wf_pk_add(dg, neq));                 // diag + neq
                 dg = left;
-                up = v + 1;
-                cp1[i] = up;
+                up = v;
+                cp[i] = v;
             }
         };
 
         int s = 0;
         for (; s < Lm - 1; ++s) { // ramp-up: lanes join one per step
-            const int recv = apm_shift_up1(cp1[R - 1]);
+            const uint32_t recv = (uint32_t)apm_shift_up1((int)cp[R - 1]);
             if (s >= y0) step(s, recv);
         }
         for (; s < nsteps; ++s) {
-            const int recv = apm_shift_up1(cp1[R - 1]);
+            const uint32_t recv = (uint32_t)apm_shift_up1((int)cp[R - 1]);
             step(s, recv);
         }
 
-        int resp1 = cp1[0];
+        uint32_t res = cp[0];
 #pragma unroll
         for (int i = 1; i < R; ++i)
-            if (i == ires) resp1 = cp1[i];
-        const int64_t j = base + joff;
-        cnt += apm_wave_count(is_res && joff < tile && j >= jb && j < je_p && resp1 <= k + 1);
+            if (i == ires) res = cp[i];
+        const int64_t jA = base + joff, jB = jA + 1;
+        const uint32_t thr = (uint32_t)(k + 1);
+        cnt += apm_wave_count(is_res && joff < tile && jA >= jb && jA < je_p && (res & 0xffffu) <= thr);
+        cnt += apm_wave_count(is_res && joff + 1 < tile && jB >= jb && jB < je_p && (res >> 16) <= thr);
     }
     return cnt;
 }
