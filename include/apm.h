@@ -62,7 +62,8 @@ typedef enum apm_status {
  *   BITPAR     full m x m DP, one window per lane, Myers/Hyyro bit-vector
  *              columns (32 DP cells per integer op), exact distance
  *   BANDED     exact for the predicate dist<=k: only diagonals |x-y|<=k/2,
- *              early exit, candidates pre-filtered by pigeonhole q-gram keys
+ *              early exit, candidates pre-filtered by pigeonhole sub-keys looked up
+ *              in an LDS hash table (needs m<=256, k<=7, m/(k+1)>=4)
  *   GENERIC    literal one-column DP per lane, any m, handles truncated tails
  *   AUTO       fastest applicable exact variant per pattern (default)        */
 typedef enum apm_kernel {

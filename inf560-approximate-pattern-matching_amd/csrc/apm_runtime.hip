@@ -71,7 +71,6 @@ struct TiledLaunch {       // host description of one tiled scan launch
     int a_max = 0;                    // BANDED: largest key offset
     int blocks_per_cu[3] = {0, 0, 0}; // BANDED: resident workgroups per CU (occupancy query, cached) [tile, tile+dma, stream]
     int m_max = 0, m_min = 0, tile = 0;
-    double cells_per_pos = 0; // sum m^2 over its patterns
 };
 
 struct GenericGroup {      // patterns scanned by the generic kernel, one launch (grid.y = pattern)
@@ -84,8 +83,6 @@ struct DevTiled {
     uint8_t *d_bytes = nullptr;
     uint32_t *d_tables = nullptr;
     uint8_t *d_lut = nullptr;
-    ApmKey *d_keys = nullptr;
-    uint16_t *d_piece_off = nullptr;
     uint8_t *d_image = nullptr;
 };
 
@@ -214,8 +211,6 @@ void free_device_plan(DeviceState &ds) {
         if (t.d_bytes) hipFree(t.d_bytes);
         if (t.d_tables) hipFree(t.d_tables);
         if (t.d_lut) hipFree(t.d_lut);
-        if (t.d_keys) hipFree(t.d_keys);
-        if (t.d_piece_off) hipFree(t.d_piece_off);
         if (t.d_image) hipFree(t.d_image);
     }
     ds.tiled.clear();
@@ -324,7 +319,6 @@ int build_plan(apm_ctx *ctx) {
                 L.descs.push_back(d);
                 L.m_max = std::max(L.m_max, pi.m);
                 L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
-                L.cells_per_pos += double(pi.m) * pi.m;
             }
             ctx->tiled.push_back(std::move(L));
         }
@@ -349,7 +343,6 @@ int build_plan(apm_ctx *ctx) {
                 L.descs.push_back(d);
                 L.m_max = std::max(L.m_max, pi.m);
                 L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
-                L.cells_per_pos += double(pi.m) * pi.m;
             }
             ctx->tiled.push_back(std::move(L));
         }
@@ -416,7 +409,6 @@ int build_plan(apm_ctx *ctx) {
                 L.descs.push_back(d);
                 L.m_max = std::max(L.m_max, pi.m);
                 L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
-                L.cells_per_pos += double(pi.m) * (2 * (ctx->k / 2) + 1);
             }
             const int band = ctx->k / 2;
             const int front = band > 0 ? 16 : 0;
@@ -518,8 +510,6 @@ int build_plan(apm_ctx *ctx) {
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_tables, L.tables))) return rc;
             std::vector<uint8_t> lut(L.lut, L.lut + 256);
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_lut, lut))) return rc;
-            if ((rc = upload_vec(ctx, &ds.tiled[t].d_keys, L.keys))) return rc;
-            if ((rc = upload_vec(ctx, &ds.tiled[t].d_piece_off, L.piece_off))) return rc;
             if ((rc = upload_vec(ctx, &ds.tiled[t].d_image, L.image))) return rc;
         }
     }
