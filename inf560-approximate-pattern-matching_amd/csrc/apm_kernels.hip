@@ -643,6 +643,79 @@ __device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t 
     }
 }
 
+// ---- hierarchical verification (per-position key classes) ---------------------------------
+// The k+1 pigeonhole pieces are paired (0,1), (2,3), ...  With <= k edits in the window some pair
+// carries <= 1 edit (or, for even k, the unpaired last piece is intact), and inside such a pair one
+// piece is intact while its partner matches the adjoining text with <= 1 edit, anchored at the
+// intact piece and free at the far end.  A key hit therefore only needs the expensive window DP if
+// (a) the rest of its piece is intact and (b) its partner extends with <= 1 edit -- two short byte
+// comparisons that reject almost every random key hit.
+// 64-bit core for n <= 8: P = pattern bytes (byte i in bits 8i..), T0/T1/T2 = 12 text bytes.
+// One edit is located by the first mismatching byte i (ctz); the three ways to spend it are checked
+// with shifted compares: substitution (P vs T), pattern byte without text counterpart (P vs T<<8),
+// one extra text byte (P vs T>>8).
+__device__ __forceinline__ bool apm_ext1_core(uint32_t p0, uint32_t p1, uint32_t t0, uint32_t t1, uint32_t t2, int n) {
+    const unsigned long long mask = n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);
+    const unsigned long long P = ((unsigned long long)p1 << 32) | p0;
+    const unsigned long long T = ((unsigned long long)t1 << 32) | t0;
+    const unsigned long long x0 = (P ^ T) & mask;
+    if (x0 == 0ull) return true;
+    const int i = __builtin_ctzll(x0) >> 3;       // first mismatching byte
+    if (i >= n - 1) return true;                  // substitution at the last byte
+    const int sh = 8 * (i + 1);
+    if ((x0 >> sh) == 0ull) return true;          // substitution at i
+    const unsigned long long xd = (P ^ (T << 8)) & mask;
+    if ((xd >> sh) == 0ull) return true;          // pattern byte i has no text counterpart
+    const unsigned long long Tp = ((unsigned long long)__builtin_amdgcn_alignbyte(t2, t1, 1u) << 32) |
+                                  __builtin_amdgcn_alignbyte(t1, t0, 1u); // text shifted down by one byte
+    const unsigned long long xi = (P ^ Tp) & mask;
+    return (xi >> (8 * i)) == 0ull;               // one extra text byte before pattern byte i
+}
+__device__ __forceinline__ uint32_t apm_bswap(uint32_t v) { return __builtin_bswap32(v); }
+
+// pattern pb[pp..pp+n) vs text read FORWARD from tb[tp]: <= 1 edit, all of the pattern consumed
+__device__ __forceinline__ bool apm_ext_fwd(const uint8_t *tb, int tp, const uint8_t *pb, int pp, int n) {
+    if (n <= 8) {
+        uint32_t P[2], T[3];
+        apm_lds_dwords<2>(pb, pp, P);
+        apm_lds_dwords<3>(tb, tp, T);
+        return apm_ext1_core(P[0], P[1], T[0], T[1], T[2], n);
+    }
+    int i = 0;
+    while (i < n && tb[tp + i] == pb[pp + i]) ++i;
+    if (i >= n - 1) return true; // no mismatch, or a single substitution at the last byte
+    bool ok = true;              // substitution at i
+    for (int j = i + 1; j < n && ok; ++j) ok = tb[tp + j] == pb[pp + j];
+    if (ok) return true;
+    ok = true;                   // pattern byte i has no text counterpart
+    for (int j = i + 1; j < n && ok; ++j) ok = tb[tp + j - 1] == pb[pp + j];
+    if (ok) return true;
+    ok = true;                   // one extra text byte before pattern byte i
+    for (int j = i; j < n && ok; ++j) ok = tb[tp + j + 1] == pb[pp + j];
+    return ok;
+}
+// pattern pb[pp..pp+n) vs text read BACKWARD from tb[te-1] (te exclusive): <= 1 edit
+__device__ __forceinline__ bool apm_ext_bwd(const uint8_t *tb, int te, const uint8_t *pb, int pp, int n) {
+    if (n <= 8) { // same core on the byte-reversed strings
+        uint32_t Q[2], W[3];
+        apm_lds_dwords<2>(pb, pp + n - 8, Q);
+        apm_lds_dwords<3>(tb, te - 12, W);
+        return apm_ext1_core(apm_bswap(Q[1]), apm_bswap(Q[0]), apm_bswap(W[2]), apm_bswap(W[1]), apm_bswap(W[0]), n);
+    }
+    int i = 0;
+    while (i < n && tb[te - 1 - i] == pb[pp + n - 1 - i]) ++i;
+    if (i >= n - 1) return true;
+    bool ok = true;
+    for (int j = i + 1; j < n && ok; ++j) ok = tb[te - 1 - j] == pb[pp + n - 1 - j];
+    if (ok) return true;
+    ok = true;
+    for (int j = i + 1; j < n && ok; ++j) ok = tb[te - j] == pb[pp + n - 1 - j];
+    if (ok) return true;
+    ok = true;
+    for (int j = i; j < n && ok; ++j) ok = tb[te - 2 - j] == pb[pp + n - 1 - j];
+    return ok;
+}
+
 // DMA = 1: tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), three LDS
 // tile buffers, waits placed by hand (vmcnt(1): the younger tile stays in flight).  Needs a 16-byte
 // aligned text pointer.  DMA = 0: register-staged buffer loads, two LDS buffers, compiler-placed waits.
@@ -670,7 +743,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
     const uint16_t *s_poff = reinterpret_cast<const uint16_t *>(s_img + a.o_poff); // piece offsets a_q
     uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_img + a.image_len); // 2 x qcap
     uint32_t *s_cnt = s_queue + 2 * a.qcap;
-    uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [3] rotating queue counters
+    uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [2] queue counters
 
     // Branch-free tile fetch: ONE raw buffer load of 16 bytes per lane per tile (tile = 4096 bytes),
     // the descriptor's num_records does the bounds check (out-of-range lanes return 0 and move no
@@ -733,7 +806,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
     for (int i = tid; i < (a.image_len >> 4); i += APM_BLOCK)
         reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
-    if (tid < 3) s_qn[tid] = 0u;
+    if (tid < 2) s_qn[tid] = 0u;
     if constexpr (!DMA) {
         if (t < a.ntiles) {
             stash(s_tile0, ra0);
@@ -744,14 +817,46 @@ void apm_filter_kernel(ApmFilterArgs a) {
     __syncthreads(); // (drains the prologue loads, DMA included)
 
     // verification of one (key, sampled text position, shift) nomination; bumps s_cnt
-    auto verify_item = [&](const uint8_t *s_tile, int64_t base, int kid, int pos, int dl) __attribute__((always_inline)) {
+    // does piece q of the pattern (piece offsets at s_poff[aux..], n_pieces of them, length m, bytes at
+    // s_pat+poff) found intact at LDS text offset tq pass the pair pre-check?  (see apm_ext_fwd)
+    constexpr bool PAIRS = (STRIDE == 1) && (BAND >= 1);
+    auto group_check = [&](const uint8_t *s_tile, int q, int tq, int aux, int n_pieces, int m, int poff) __attribute__((always_inline)) {
+        if constexpr (!PAIRS) {
+            return true;
+        } else {
+            const int aq = (int)s_poff[aux + q];
+            const int aq1 = (q + 1 < n_pieces) ? (int)s_poff[aux + q + 1] : m;
+            for (int x = KL; x < aq1 - aq; ++x) // rest of the piece behind its key bytes
+                if (s_tile[tq + x] != s_pat[poff + aq + x]) return false;
+            const int p = q ^ 1;
+            if (p >= n_pieces) return true; // unpaired last piece (even k)
+            if (p > q) {
+                const int ap1 = (p + 1 < n_pieces) ? (int)s_poff[aux + p + 1] : m;
+                return apm_ext_fwd(s_tile, tq + (aq1 - aq), s_pat, poff + aq1, ap1 - aq1);
+            }
+            const int ap = (int)s_poff[aux + p];
+            return apm_ext_bwd(s_tile, tq, s_pat, poff + ap, aq - ap);
+        }
+    };
+
+    // stage 1 of a nomination (key, sampled text position): key bytes equal + pair pre-check
+    auto stage1_item = [&](const uint8_t *s_tile, int kid, int pos) __attribute__((always_inline)) {
+        const uint32_t ki = s_kinfo[kid];
+        const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kpiece = (int)((ki >> 21) & 7u);
+        const uint2 pinf = s_pinfo[kpat];
+        const int poff = (int)(pinf.x & 0xffffu);
+        if (!apm_key_equal<KL>(s_tile, pos, s_pat, poff + koff)) return false; // fingerprint collision
+        return (bool)group_check(s_tile, kpiece, pos, (int)pinf.y, a.k + 1, (int)(pinf.x >> 16), poff);
+    };
+    // stage 2: banded DP of the window the nomination implies under shift dl + stateless dedup; bumps s_cnt
+    auto dp_item = [&](const uint8_t *s_tile, int64_t base, int kid, int pos, int dl) __attribute__((always_inline)) {
         const uint32_t ki = s_kinfo[kid];
         struct { int pat, off, piece; } key = {(int)(ki & 0xfffu), (int)((ki >> 12) & 0x1ffu), (int)((ki >> 21) & 7u)};
         const uint2 pinf = s_pinfo[key.pat];
         struct { int m, aux_off; } d = {(int)(pinf.x >> 16), (int)pinf.y};
         const int poff = (int)(pinf.x & 0xffffu);
-        if (!apm_key_equal<KL>(s_tile, pos, s_pat, poff + (int)key.off)) return; // fingerprint collision
         const int m = d.m;
+        const int n_pieces = a.k + 1;
         const int64_t je_p = min(a.je, a.nrel - m + 1);
         const int jr = pos - a.front - key.off - dl; // window start relative to base
         const int64_t j = base + jr;
@@ -764,10 +869,16 @@ void apm_filter_kernel(ApmFilterArgs a) {
                 if (qq == (int)key.piece && dd >= dl) break;
                 const int o = a.front + jr + aq + dd;           // piece start under shift dd
                 const int rr = (STRIDE - (o % STRIDE)) % STRIDE; // its sampled (aligned) block
-                if (apm_key_equal<KL>(s_tile, o + rr, s_pat, poff + aq + rr)) return;
+                if (apm_key_equal<KL>(s_tile, o + rr, s_pat, poff + aq + rr) &&
+                    group_check(s_tile, qq, o, d.aux_off, n_pieces, m, poff))
+                    return;
             }
         }
         atomicAdd(&s_cnt[key.pat], 1u);
+    };
+    auto verify_item = [&](const uint8_t *s_tile, int64_t base, int kid, int pos, int dl_lo, int dl_hi) __attribute__((always_inline)) {
+        if (!stage1_item(s_tile, kid, pos)) return;
+        for (int dl = dl_lo; dl <= dl_hi; ++dl) dp_item(s_tile, base, kid, pos, dl);
     };
 
     const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
@@ -838,7 +949,8 @@ void apm_filter_kernel(ApmFilterArgs a) {
         constexpr int NSH = 2 * BAND + 1;
         // all keys whose tag matches at this sampled position (bucket ways, overflow list, chains);
         // one runtime loop = ONE inlined copy of the verification code
-        auto for_each_key = [&](uint32_t tag, int pos, int dl) __attribute__((always_inline)) {
+        auto for_each_key = [&](uint32_t tag, int pos, int dl_lo, int dl_hi) __attribute__((always_inline)) {
+            auto handle = [&](int kid) __attribute__((always_inline)) { verify_item(s_tile, base, kid, pos, dl_lo, dl_hi); };
             uint32_t fw[(KL + 3) / 4];
             apm_lds_dwords<(KL + 3) / 4>(s_tile, pos, fw);
             uint32_t fi;
@@ -848,29 +960,30 @@ void apm_filter_kernel(ApmFilterArgs a) {
             const uint32_t slot = apm_table_hash<KL>(fi) >> hshift;
             const uint16_t *tag16 = reinterpret_cast<const uint16_t *>(s_tab + slot);
             const uint16_t *kid16p = reinterpret_cast<const uint16_t *>(s_kid + slot);
-            // Find this lane's matching way first (cheap scan), THEN verify: all lanes of the wave run the
-            // banded DP together instead of once per way index with 1/8 of the lanes active.
+            // Find this lane's matching way first (one 16-byte read of the tags, one of the key ids), THEN
+            // verify: all lanes of the wave run the checks together instead of once per way index.
             uint32_t first = 0xffffffffu;
             int n_match = 0;
-#pragma unroll 1
-            for (int c = 0; c < 8 + a.n_ovf; ++c) {
-                uint32_t t16, kid16;
-                if (c < 8) {
-                    t16 = tag16[c];
-                    kid16 = kid16p[c];
-                } else {
-                    t16 = s_ovf[2 * (c - 8)];
-                    kid16 = s_ovf[2 * (c - 8) + 1];
+            {
+                const uint4 tg = s_tab[slot], kd = s_kid[slot];
+                const uint32_t tw[4] = {tg.x, tg.y, tg.z, tg.w}, kw[4] = {kd.x, kd.y, kd.z, kd.w};
+#pragma unroll
+                for (int wv = 3; wv >= 0; --wv) { // descending: `first` ends up as the lowest matching way
+                    const uint32_t khi = kw[wv] >> 16, klo = kw[wv] & 0xffffu;
+                    if ((tw[wv] >> 16) == tag && khi != 0xffffu) { first = khi; ++n_match; }
+                    if ((tw[wv] & 0xffffu) == tag && klo != 0xffffu) { first = klo; ++n_match; }
                 }
-                if (t16 != tag || kid16 == 0xffffu) continue;
-                if (n_match == 0) first = kid16;
-                ++n_match;
+                for (int o = 0; o < a.n_ovf; ++o) // ascending: same "first" as the walk below
+                    if (s_ovf[2 * o] == tag) {
+                        if (n_match == 0) first = s_ovf[2 * o + 1];
+                        ++n_match;
+                    }
             }
             if (n_match > 0) {
                 uint32_t kid = first & 0x7fffu;
                 const bool more = (first & 0x8000u) != 0; // heads a chain of keys with the same tag
                 for (;;) {
-                    verify_item(s_tile, base, (int)kid, pos, dl);
+                    handle((int)kid);
                     if (!more) break;
                     const uint32_t nxt = s_next[kid];
                     if (!nxt) break;
@@ -894,7 +1007,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
                     uint32_t kid = kid16 & 0x7fffu;
                     const bool more = (kid16 & 0x8000u) != 0;
                     for (;;) {
-                        verify_item(s_tile, base, (int)kid, pos, dl);
+                        handle((int)kid);
                         if (!more) break;
                         const uint32_t nxt = s_next[kid];
                         if (!nxt) break;
@@ -904,17 +1017,23 @@ void apm_filter_kernel(ApmFilterArgs a) {
             }
         };
         if (a.ablate & 8) { // measurement aid: skip verification
-        } else if (qn <= (uint32_t)a.qcap) { // work item = (queue entry, shift): keeps all lanes busy
-            for (uint32_t wi = tid; wi < qn * NSH; wi += APM_BLOCK) {
-                const uint32_t ent = queue[wi / NSH];
-                for_each_key(ent >> 16, (int)(ent & 0xffffu), (int)(wi % NSH) - BAND);
+        } else if (qn <= (uint32_t)a.qcap) {
+            if constexpr (PAIRS) { // work item = queue entry: the cheap pair pre-check runs once, shifts inside
+                for (uint32_t wi = tid; wi < qn; wi += APM_BLOCK) {
+                    const uint32_t ent = queue[wi];
+                    for_each_key(ent >> 16, (int)(ent & 0xffffu), -BAND, BAND);
+                }
+            } else { // work item = (queue entry, shift): keeps all lanes busy
+                for (uint32_t wi = tid; wi < qn * NSH; wi += APM_BLOCK) {
+                    const uint32_t ent = queue[wi / NSH];
+                    const int dl = (int)(wi % NSH) - BAND;
+                    for_each_key(ent >> 16, (int)(ent & 0xffffu), dl, dl);
+                }
             }
-        } else { // queue overflow: dense pass over every (sampled position, key, shift)
+        } else { // queue overflow: dense pass over every (sampled position, key)
             for (int i = 0; i < NF; ++i)
-                for (int kid = 0; kid < a.nk; ++kid)
-                    for (int dl = -BAND; dl <= BAND; ++dl) verify_item(s_tile, base, kid, p0 + i * STRIDE, dl);
+                for (int kid = 0; kid < a.nk; ++kid) verify_item(s_tile, base, kid, p0 + i * STRIDE, -BAND, BAND);
         }
-
     };
 
     if constexpr (DMA) {
