@@ -1077,18 +1077,78 @@ void apm_filter_kernel(ApmFilterArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// STREAM form of the BANDED filter for the sampled classes (STRIDE == KL, 16 or 8).
-// A sampled fingerprint needs only the lane's own 16 bytes, so nothing is shared between lanes
-// while filtering: every WAVE is autonomous -- no LDS text tile, no workgroup barrier in the loop.
-// A wave walks 1 KiB chunks (16 bytes per lane, chunks c, c+W, c+2W, ... for W waves in flight),
-// keeps four buffer loads per lane in flight, probes the LDS hash table, and collects the rare
-// hits in a wave-private LDS queue (ballot + mbcnt, no atomics).  When the queue holds a wave's
-// worth of work it is verified on the spot: candidate windows are read back from global memory
-// (they were streamed moments ago: L2 / Infinity Cache hits), same banded DP + stateless dedup.
+// STREAM form of the BANDED filter: every WAVE is autonomous -- no LDS text tile, no workgroup
+// barrier in the loop.  A wave walks 1 KiB chunks (16 bytes per lane; chunks c, c+W, c+2W, ... for W
+// waves in flight) and keeps four buffer loads per lane in flight.  Sampled classes (STRIDE == KL)
+// fingerprint the lane's own 16 bytes; per-position classes (STRIDE == 1) also fetch the 8 bytes
+// that follow them.  Fingerprints probe the LDS hash table; the hits go to a wave-private LDS queue
+// (ballot + mbcnt, no atomics).  When the queue holds a wave's worth of work it is verified on the
+// spot against global memory (the bytes were streamed moments ago: L2 / Infinity Cache hits): key
+// compare, pair pre-check (per-position classes), banded DP, stateless dedup.
 // Requires a 16-byte aligned text pointer (sampling grid = address grid).
 // ---------------------------------------------------------------------------
-template <int BAND, int KL>
-__global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kernel(ApmFilterArgs a) {
+// N dwords of text starting at relative position off (any alignment), zero beyond [0, limit)
+template <int N>
+__device__ __forceinline__ void apm_gdwords(const uint8_t *text, int64_t limit, int64_t off, uint32_t (&out)[N]) {
+    const int64_t a0 = off & ~(int64_t)3;
+    const uint32_t sh = (uint32_t)off & 3u;
+    uint32_t w[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) {
+        const int64_t q = a0 + 4 * i;
+        w[i] = (q >= 0 && q + 4 <= limit) ? *reinterpret_cast<const uint32_t *>(text + q) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+}
+__device__ __forceinline__ int apm_gbyte(const uint8_t *text, int64_t limit, int64_t off) {
+    return (off >= 0 && off < limit) ? (int)text[off] : 0x100;
+}
+// global-text versions of apm_ext_fwd / apm_ext_bwd (see there)
+__device__ __forceinline__ bool apm_ext_fwd_g(const uint8_t *text, int64_t limit, int64_t tp, const uint8_t *pb, int pp, int n) {
+    if (n <= 8) {
+        uint32_t P[2], T[3];
+        apm_lds_dwords<2>(pb, pp, P);
+        apm_gdwords<3>(text, limit, tp, T);
+        return apm_ext1_core(P[0], P[1], T[0], T[1], T[2], n);
+    }
+    int i = 0;
+    while (i < n && apm_gbyte(text, limit, tp + i) == (int)pb[pp + i]) ++i;
+    if (i >= n - 1) return true;
+    bool ok = true;
+    for (int j = i + 1; j < n && ok; ++j) ok = apm_gbyte(text, limit, tp + j) == (int)pb[pp + j];
+    if (ok) return true;
+    ok = true;
+    for (int j = i + 1; j < n && ok; ++j) ok = apm_gbyte(text, limit, tp + j - 1) == (int)pb[pp + j];
+    if (ok) return true;
+    ok = true;
+    for (int j = i; j < n && ok; ++j) ok = apm_gbyte(text, limit, tp + j + 1) == (int)pb[pp + j];
+    return ok;
+}
+__device__ __forceinline__ bool apm_ext_bwd_g(const uint8_t *text, int64_t limit, int64_t te, const uint8_t *pb, int pp, int n) {
+    if (n <= 8) {
+        uint32_t Q[2], W[3];
+        apm_lds_dwords<2>(pb, pp + n - 8, Q);
+        apm_gdwords<3>(text, limit, te - 12, W);
+        return apm_ext1_core(apm_bswap(Q[1]), apm_bswap(Q[0]), apm_bswap(W[2]), apm_bswap(W[1]), apm_bswap(W[0]), n);
+    }
+    int i = 0;
+    while (i < n && apm_gbyte(text, limit, te - 1 - i) == (int)pb[pp + n - 1 - i]) ++i;
+    if (i >= n - 1) return true;
+    bool ok = true;
+    for (int j = i + 1; j < n && ok; ++j) ok = apm_gbyte(text, limit, te - 1 - j) == (int)pb[pp + n - 1 - j];
+    if (ok) return true;
+    ok = true;
+    for (int j = i + 1; j < n && ok; ++j) ok = apm_gbyte(text, limit, te - j) == (int)pb[pp + n - 1 - j];
+    if (ok) return true;
+    ok = true;
+    for (int j = i; j < n && ok; ++j) ok = apm_gbyte(text, limit, te - 2 - j) == (int)pb[pp + n - 1 - j];
+    return ok;
+}
+
+template <int BAND, int KL, int STRIDE>
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 3 || STRIDE == 1) ? 4 : 5))
+void apm_stream_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // provably wave-uniform: descriptors stay in SGPRs
@@ -1096,10 +1156,11 @@ __global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kerne
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
-    constexpr int STRIDE = KL;
-    constexpr int NF = 16 / KL;
+    constexpr int NF = 16 / STRIDE;
     constexpr int NSH = 2 * BAND + 1;
-    constexpr int QW = 64 * NF + 64; // wave queue entries: flushed as soon as it holds >= 64
+    constexpr bool PAIRS = (STRIDE == 1) && (BAND >= 1);
+    constexpr int GRP = NF < 4 ? NF : 4;    // probes between two flush checks
+    constexpr int QW = 64 * GRP + 64;       // wave queue entries: flushed as soon as it holds >= 64
     uint8_t *s_img = smem;
     uint8_t *s_pat = s_img;
     const uint4 *s_tab = reinterpret_cast<const uint4 *>(s_img + a.o_tab);
@@ -1119,92 +1180,128 @@ __global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kerne
     const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
     const int64_t W = (int64_t)a.n_main_blocks * (APM_BLOCK / 64);
     const int64_t nch = a.ntiles; // 1 KiB chunks from relative position a.tile0 (multiple of 16)
+    const uint8_t *text = a.text;
+    const int64_t limit = a.avail_pad;
 
-    auto load_chunk = [&](int64_t cc) __attribute__((always_inline)) {
+    auto load_chunk = [&](int64_t cc, u32x4 &r, uint2 &e) __attribute__((always_inline)) {
         const int64_t g = a.tile0 + cc * 1024;
         const int64_t lim = cc < nch ? a.avail_pad - g : 0; // chunks past the end: zero records -> zeros, no traffic
-        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1024 ? 1024u : (uint32_t)lim);
+        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1040 ? 1040u : (uint32_t)lim);
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
-        return __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+        if constexpr (STRIDE == 1) { // the 8 bytes behind the lane's 16 (next lane's / next chunk's head)
+            typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+            const u32x2v x = __builtin_amdgcn_raw_buffer_load_b64(rs, 16 * lane + 16, 0, 0);
+            e = make_uint2(x.x, x.y);
+        }
     };
 
-    // ---- verification of one (key, sampled position, shift) nomination against global text ----
-    auto verify_item = [&](int kid, int64_t pos, int dl) __attribute__((always_inline)) {
+    // text[tpos..+KL) == pattern bytes [ppos..+KL) of the pattern stored at s_pat+poff ?
+    auto key_at = [&](int64_t tpos, int poff, int ppos) __attribute__((always_inline)) {
+        constexpr int ND = (KL + 3) / 4;
+        uint32_t x[ND], y[ND];
+        apm_lds_dwords<ND>(s_pat, poff + ppos, y);
+        apm_gdwords<ND>(text, limit, tpos, x);
+        uint32_t dd = 0;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            uint32_t tt = x[i] ^ y[i];
+            if (i == ND - 1 && (KL & 3)) tt &= (1u << (8 * (KL & 3))) - 1u;
+            dd |= tt;
+        }
+        return dd == 0u;
+    };
+    // pair pre-check of piece q found intact at text position tq (see apm_ext_fwd)
+    auto group_check = [&](int q, int64_t tq, int aux, int n_pieces, int m, int poff) __attribute__((always_inline)) {
+        if constexpr (!PAIRS) {
+            return true;
+        } else {
+            const int aq = (int)s_poff[aux + q];
+            const int aq1 = (q + 1 < n_pieces) ? (int)s_poff[aux + q + 1] : m;
+            for (int x = KL; x < aq1 - aq; ++x) // rest of the piece behind its key bytes
+                if (apm_gbyte(text, limit, tq + x) != (int)s_pat[poff + aq + x]) return false;
+            const int p = q ^ 1;
+            if (p >= n_pieces) return true; // unpaired last piece (even k)
+            if (p > q) {
+                const int ap1 = (p + 1 < n_pieces) ? (int)s_poff[aux + p + 1] : m;
+                return apm_ext_fwd_g(text, limit, tq + (aq1 - aq), s_pat, poff + aq1, ap1 - aq1);
+            }
+            const int ap = (int)s_poff[aux + p];
+            return apm_ext_bwd_g(text, limit, tq, s_pat, poff + ap, aq - ap);
+        }
+    };
+
+    // ---- verification of one (key, sampled position) nomination over shifts [dl_lo, dl_hi] ----
+    auto verify_item = [&](int kid, int64_t pos, int dl_lo, int dl_hi) __attribute__((always_inline)) {
         const uint32_t ki = s_kinfo[kid];
         const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kpiece = (int)((ki >> 21) & 7u);
         const uint2 pinf = s_pinfo[kpat];
         const int m = (int)(pinf.x >> 16), aux = (int)pinf.y, poff = (int)(pinf.x & 0xffffu);
-        auto key_at = [&](int64_t tpos, int ppos) __attribute__((always_inline)) { // text[tpos..+KL) == pattern[ppos..+KL) ?
-            uint32_t y[KL / 4];
-            apm_lds_dwords<KL / 4>(s_pat, poff + ppos, y);
-            uint32_t dd;
-            if constexpr (KL == 16) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(a.text + tpos);
-                dd = (x.x ^ y[0]) | (x.y ^ y[1]) | (x.z ^ y[2]) | (x.w ^ y[3]);
-            } else {
-                const uint2 x = *reinterpret_cast<const uint2 *>(a.text + tpos);
-                dd = (x.x ^ y[0]) | (x.y ^ y[1]);
-            }
-            return dd == 0u;
-        };
-        if (!key_at(pos, koff)) return; // fingerprint / tag collision
+        const int n_pieces = a.k + 1;
+        if (!key_at(pos, poff, koff)) return; // fingerprint / tag collision
+        if (!group_check(kpiece, pos, aux, n_pieces, m, poff)) return;
         const int64_t je_p = min(a.je, a.nrel - m + 1);
-        const int64_t j = pos - koff - dl; // candidate window start
-        if (j < a.jb || j >= je_p) return;
-        if (!apm_banded_verify<BAND>(ApmGlobalText{a.text, j, a.avail_pad}, s_pat, poff, m, a.k)) return;
-        // count the window once: only from its first true (piece, shift) nominator
-        for (int qq = 0; qq <= kpiece; ++qq) {
-            const int aq = (int)s_poff[aux + qq];
-            for (int dd = -BAND; dd <= BAND; ++dd) {
-                if (qq == kpiece && dd >= dl) break;
-                const int64_t o = j + aq + dd;                                   // piece start under shift dd
-                const int rr = (int)((STRIDE - (o & (STRIDE - 1))) & (STRIDE - 1)); // its sampled (aligned) block
-                if (o + rr >= 0 && key_at(o + rr, aq + rr)) return;
+        for (int dl = dl_lo; dl <= dl_hi; ++dl) {
+            const int64_t j = pos - koff - dl; // candidate window start
+            if (j < a.jb || j >= je_p) continue;
+            if (!apm_banded_verify<BAND>(ApmGlobalText{text, j, limit}, s_pat, poff, m, a.k)) continue;
+            // count the window once: only from its first true (piece, shift) nominator
+            bool first = true;
+            for (int qq = 0; qq <= kpiece && first; ++qq) {
+                const int aq = (int)s_poff[aux + qq];
+                for (int dd = -BAND; dd <= BAND; ++dd) {
+                    if (qq == kpiece && dd >= dl) break;
+                    const int64_t o = j + aq + dd;                                   // piece start under shift dd
+                    const int rr = (int)((STRIDE - (o & (STRIDE - 1))) & (STRIDE - 1)); // its sampled (aligned) block
+                    if (o + rr >= 0 && key_at(o + rr, poff, aq + rr) && group_check(qq, o, aux, n_pieces, m, poff)) {
+                        first = false;
+                        break;
+                    }
+                }
             }
+            if (first) atomicAdd(&s_cnt[kpat], 1u);
         }
-        atomicAdd(&s_cnt[kpat], 1u);
     };
 
     auto flush = [&](uint32_t qcount) __attribute__((always_inline)) {
-        for (uint32_t wi = lane; wi < qcount * NSH; wi += 64) {
-            const uint2 ent = s_queue[wi / NSH];
-            const int dl = (int)(wi % NSH) - BAND;
+        const uint32_t nitems = PAIRS ? qcount : qcount * NSH; // PAIRS: the cheap pre-check runs once per entry
+        for (uint32_t wi = lane; wi < nitems; wi += 64) {
+            const uint2 ent = s_queue[PAIRS ? wi : wi / NSH];
+            const int dl_lo = PAIRS ? -BAND : (int)(wi % NSH) - BAND;
+            const int dl_hi = PAIRS ? BAND : dl_lo;
             const uint32_t tag = ent.y & 0xffffu;
             const int64_t pos = (int64_t)ent.x | ((int64_t)(ent.y >> 16) << 32);
             if (pos + KL > a.avail) continue;
+            uint32_t fw[(KL + 3) / 4];
+            apm_gdwords<(KL + 3) / 4>(text, limit, pos, fw);
             uint32_t fi;
-            if constexpr (KL == 16) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(a.text + pos);
-                fi = apm_fp16(apm_fp8(x.x, x.y), apm_fp8(x.z, x.w));
-            } else {
-                const uint2 x = *reinterpret_cast<const uint2 *>(a.text + pos);
-                fi = apm_fp8(x.x, x.y);
-            }
+            if constexpr (KL == 16) fi = apm_fp16(apm_fp8(fw[0], fw[1]), apm_fp8(fw[2], fw[3]));
+            else if constexpr (KL > 4) fi = apm_fp8(fw[0], fw[1] & apm_hi_mask<KL>());
+            else fi = fw[0];
             const uint32_t slot = apm_table_hash<KL>(fi) >> hshift;
-            const uint16_t *tag16 = reinterpret_cast<const uint16_t *>(s_tab + slot);
-            const uint16_t *kid16p = reinterpret_cast<const uint16_t *>(s_kid + slot);
-            uint32_t first = 0xffffffffu; // this lane's matching way (cheap scan), verified with the whole wave
+            uint32_t first = 0xffffffffu; // this lane's matching way, verified with the whole wave
             int n_match = 0;
-#pragma unroll 1
-            for (int c = 0; c < 8 + a.n_ovf; ++c) {
-                uint32_t t16, kid16;
-                if (c < 8) {
-                    t16 = tag16[c];
-                    kid16 = kid16p[c];
-                } else {
-                    t16 = s_ovf[2 * (c - 8)];
-                    kid16 = s_ovf[2 * (c - 8) + 1];
+            {
+                const uint4 tg = s_tab[slot], kd = s_kid[slot];
+                const uint32_t tw[4] = {tg.x, tg.y, tg.z, tg.w}, kw[4] = {kd.x, kd.y, kd.z, kd.w};
+#pragma unroll
+                for (int w4 = 3; w4 >= 0; --w4) { // descending: `first` ends up as the lowest matching way
+                    const uint32_t khi = kw[w4] >> 16, klo = kw[w4] & 0xffffu;
+                    if ((tw[w4] >> 16) == tag && khi != 0xffffu) { first = khi; ++n_match; }
+                    if ((tw[w4] & 0xffffu) == tag && klo != 0xffffu) { first = klo; ++n_match; }
                 }
-                if (t16 != tag || kid16 == 0xffffu) continue;
-                if (n_match == 0) first = kid16;
-                ++n_match;
+                for (int o = 0; o < a.n_ovf; ++o)
+                    if (s_ovf[2 * o] == tag) {
+                        if (n_match == 0) first = s_ovf[2 * o + 1];
+                        ++n_match;
+                    }
             }
             if (n_match > 0) {
                 uint32_t kid = first & 0x7fffu;
                 const bool more = (first & 0x8000u) != 0;
                 for (;;) {
-                    verify_item((int)kid, pos, dl);
+                    verify_item((int)kid, pos, dl_lo, dl_hi);
                     if (!more) break;
                     const uint32_t nxt = s_next[kid];
                     if (!nxt) break;
@@ -1212,6 +1309,8 @@ __global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kerne
                 }
             }
             if (n_match > 1) { // several ways carry this tag (rare)
+                const uint16_t *tag16 = reinterpret_cast<const uint16_t *>(s_tab + slot);
+                const uint16_t *kid16p = reinterpret_cast<const uint16_t *>(s_kid + slot);
                 int seen = 0;
 #pragma unroll 1
                 for (int c = 0; c < 8 + a.n_ovf; ++c) {
@@ -1228,7 +1327,7 @@ __global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kerne
                     uint32_t kid = kid16 & 0x7fffu;
                     const bool more = (kid16 & 0x8000u) != 0;
                     for (;;) {
-                        verify_item((int)kid, pos, dl);
+                        verify_item((int)kid, pos, dl_lo, dl_hi);
                         if (!more) break;
                         const uint32_t nxt = s_next[kid];
                         if (!nxt) break;
@@ -1253,34 +1352,80 @@ __global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kerne
         for (int o = 0; o < a.n_ovf; ++o) hit |= (s_ovf[2 * o] == tag);
         hit &= valid;
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-        if (mask) { // rare
+        if (mask) { // rare with long keys
             const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             if (hit) s_queue[idx] = make_uint2((uint32_t)pos, ((uint32_t)(pos >> 32) << 16) | tag);
             qcount += (uint32_t)__builtin_popcountll(mask);
         }
     };
-    auto process = [&](const u32x4 &v, int64_t cc) __attribute__((always_inline)) {
-        const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
-        const bool valid = cc < nch && !(a.ablate & 1);
-        if constexpr (KL == 16) {
-            probe(apm_fp16(apm_fp8(v.x, v.y), apm_fp8(v.z, v.w)), pos, valid);
-        } else {
-            probe(apm_fp8(v.x, v.y), pos, valid);
-            probe(apm_fp8(v.z, v.w), pos + 8, valid);
-        }
+    auto drain = [&]() __attribute__((always_inline)) {
         if (qcount >= 64u) {
             flush(qcount);
             qcount = 0;
         }
     };
+    auto process = [&](const u32x4 &v, const uint2 &e, int64_t cc) __attribute__((always_inline)) {
+        const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
+        const bool valid = cc < nch && !(a.ablate & 1);
+        if constexpr (STRIDE == 16) {
+            probe(apm_fp16(apm_fp8(v.x, v.y), apm_fp8(v.z, v.w)), pos, valid);
+            drain();
+        } else if constexpr (STRIDE == 8) {
+            probe(apm_fp8(v.x, v.y), pos, valid);
+            probe(apm_fp8(v.z, v.w), pos + 8, valid);
+            drain();
+        } else { // every position, KL = 8, 6 or 4 key bytes: four groups of four probes, ONE drain site
+            const uint32_t w[6] = {v.x, v.y, v.z, v.w, e.x, e.y};
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {
+                uint32_t wa, wb, wc; // the three dwords covering positions 4g .. 4g+3 (+ 8 key bytes)
+                switch (g) {
+                case 0: wa = w[0]; wb = w[1]; wc = w[2]; break;
+                case 1: wa = w[1]; wb = w[2]; wc = w[3]; break;
+                case 2: wa = w[2]; wb = w[3]; wc = w[4]; break;
+                default: wa = w[3]; wb = w[4]; wc = w[5]; break;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t lo = i ? __builtin_amdgcn_alignbyte(wb, wa, (uint32_t)i) : wa;
+                    uint32_t fi = lo;
+                    if constexpr (KL > 4) {
+                        const uint32_t hi = i ? __builtin_amdgcn_alignbyte(wc, wb, (uint32_t)i) : wb;
+                        fi = apm_fp8(lo, hi & apm_hi_mask<KL>());
+                    }
+                    probe(fi, pos + 4 * g + i, valid);
+                }
+                drain();
+            }
+        }
+    };
 
     int64_t c = (int64_t)blockIdx.x * (APM_BLOCK / 64) + wv;
-    u32x4 r0 = load_chunk(c), r1 = load_chunk(c + W), r2 = load_chunk(c + 2 * W), r3 = load_chunk(c + 3 * W);
-    for (; c < nch; c += 4 * W) {
-        { const u32x4 v = r0; r0 = load_chunk(c + 4 * W); process(v, c); }
-        { const u32x4 v = r1; r1 = load_chunk(c + 5 * W); process(v, c + W); }
-        { const u32x4 v = r2; r2 = load_chunk(c + 6 * W); process(v, c + 2 * W); }
-        { const u32x4 v = r3; r3 = load_chunk(c + 7 * W); process(v, c + 3 * W); }
+    if constexpr (STRIDE == 1) {
+        // probe-bound classes: one chunk in flight per lane is enough (several waves per SIMD overlap),
+        // and ONE process site keeps a single copy of the verification code
+        u32x4 r;
+        uint2 e = make_uint2(0, 0);
+        load_chunk(c, r, e);
+        for (; c < nch; c += W) {
+            const u32x4 v = r;
+            const uint2 ev = e;
+            load_chunk(c + W, r, e);
+            process(v, ev, c);
+        }
+    } else {
+        u32x4 r0, r1, r2, r3;
+        uint2 e0 = make_uint2(0, 0), e1 = e0, e2 = e0, e3 = e0;
+        load_chunk(c, r0, e0);
+        load_chunk(c + W, r1, e1);
+        load_chunk(c + 2 * W, r2, e2);
+        load_chunk(c + 3 * W, r3, e3);
+        for (; c < nch; c += 4 * W) {
+            { const u32x4 v = r0; const uint2 e = e0; load_chunk(c + 4 * W, r0, e0); process(v, e, c); }
+            { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 5 * W, r1, e1); process(v, e, c + W); }
+            { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 6 * W, r2, e2); process(v, e, c + 2 * W); }
+            { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 7 * W, r3, e3); process(v, e, c + 3 * W); }
+        }
     }
     flush(qcount);
 
@@ -1292,30 +1437,34 @@ __global__ __launch_bounds__(APM_BLOCK, BAND == 0 ? 8 : 6) void apm_stream_kerne
 }
 
 static size_t apm_stream_lds_bytes(const ApmFilterArgs &a) {
-    const size_t qw = (size_t)(64 * (16 / a.key_len) + 64);
+    const int nf = 16 / a.stride;
+    const size_t qw = (size_t)(64 * (nf < 4 ? nf : 4) + 64);
     size_t b = (size_t)a.image_len + 4 * qw * 8 + (size_t)((a.n_pats + 3) & ~3) * 4 + 16;
     return b < 4608 ? 4608 : b; // the tail workgroups need 256 uint4 + 128 bytes
 }
 
 template <int BAND>
-static const void *apm_stream_fn_kl(int kl) {
-    if (kl == 16) return (const void *)apm_stream_kernel<BAND, 16>;
-    if (kl == 8) return (const void *)apm_stream_kernel<BAND, 8>;
+static const void *apm_stream_fn_kl(int kl, int stride) {
+    if (kl == 16 && stride == 16) return (const void *)apm_stream_kernel<BAND, 16, 16>;
+    if (kl == 8 && stride == 8) return (const void *)apm_stream_kernel<BAND, 8, 8>;
+    // The per-position classes (stride 1) are NOT instantiated: measured on MI355X the wave-autonomous
+    // form loses to the LDS-tile kernel there (verification against global text, whole-wave DP after a
+    // single lane's pre-check: cfg5 20 ms vs 4.9 ms per GiB), so they stay on apm_filter_kernel.
     return nullptr;
 }
-static const void *apm_stream_fn(int band, int kl) {
+static const void *apm_stream_fn(int band, int kl, int stride) {
     switch (band) {
-    case 0: return apm_stream_fn_kl<0>(kl);
-    case 1: return apm_stream_fn_kl<1>(kl);
-    case 2: return apm_stream_fn_kl<2>(kl);
-    case 3: return apm_stream_fn_kl<3>(kl);
+    case 0: return apm_stream_fn_kl<0>(kl, stride);
+    case 1: return apm_stream_fn_kl<1>(kl, stride);
+    case 2: return apm_stream_fn_kl<2>(kl, stride);
+    case 3: return apm_stream_fn_kl<3>(kl, stride);
     default: return nullptr;
     }
 }
 
 int apm_stream_blocks_per_cu(const ApmFilterArgs &a) {
     int per_cu = 0;
-    const void *fn = apm_stream_fn(a.band, a.key_len);
+    const void *fn = apm_stream_fn(a.band, a.key_len, a.stride);
     if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, APM_BLOCK, apm_stream_lds_bytes(a)) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();
         per_cu = 2;
@@ -1326,7 +1475,7 @@ int apm_stream_blocks_per_cu(const ApmFilterArgs &a) {
 // a.tile0 = first scanned relative position (multiple of 16), a.ntiles = number of 1 KiB chunks
 hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t s) {
     if (a.ntiles <= 0 || a.n_pats <= 0) return hipSuccess;
-    const void *fn = apm_stream_fn(a.band, a.key_len);
+    const void *fn = apm_stream_fn(a.band, a.key_len, a.stride);
     if (!fn) return hipErrorInvalidValue;
     const int64_t want = (a.ntiles + 3) / 4;
     const int64_t cap = max_blocks < 1 ? 1 : max_blocks;

@@ -638,9 +638,10 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 static const int dma_env = getenv("APM_FILTER_DMA") ? atoi(getenv("APM_FILTER_DMA")) : 1;
                 f.use_dma = (dma_env && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) ? 1 : 0;
             }
+            // APM_FILTER_STREAM=0 forces the tile kernel (A/B aid); default: stream kernel for the sampled classes
             static const int stream_env = getenv("APM_FILTER_STREAM") ? atoi(getenv("APM_FILTER_STREAM")) : 1;
             if (stream_env && L.stride > 1 && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
-                // sampled classes: wave-autonomous streaming kernel over 1 KiB chunks
+                // wave-autonomous streaming kernel over 1 KiB chunks
                 const int64_t p_lo = std::max<int64_t>(0, jb - f.band) & ~(int64_t)15;
                 const int64_t p_hi = std::min<int64_t>(avail, je_l + L.m_max + f.band);
                 f.tile0 = p_lo;
