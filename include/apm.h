@@ -129,6 +129,14 @@ int apm_count_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *co
 /* 64-bit chunked file ingest (replaces read_input_file, src/utils.c:12-68). */
 int apm_count_file(apm_ctx *ctx, const char *path, uint64_t *counts);
 
+/* Match positions (no reference equivalent: the reference only counts, src/sequential.c:138-140).
+ * Start offsets j of the windows of pattern `pattern_index` (of the current pattern set) with
+ * dist <= k, ascending, for the whole text.  *n_found = total number of matches; at most `capacity`
+ * positions are written (if *n_found > capacity they are an arbitrary subset: retry with a larger
+ * buffer).  Runs the one pattern through the full-DP kernels; the pattern set is left unchanged. */
+int apm_find_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, int pattern_index, uint64_t *positions,
+                    uint64_t capacity, uint64_t *n_found);
+
 /* ---- shard-level API (device-resident text, asynchronous) ----
  * d_text holds the bytes of global positions [text_off, text_off+text_len) on
  * the context's device.  Counts every window whose START j lies in

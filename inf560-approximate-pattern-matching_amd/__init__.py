@@ -26,7 +26,7 @@ KERNEL_IDS = {v: k for k, v in KERNEL_NAMES.items()}
 ABI_SYMBOLS = [
     "apm_device_count", "apm_abi_version", "apm_create", "apm_create_on_device", "apm_destroy",
     "apm_last_error", "apm_set_stream", "apm_set_patterns", "apm_set_kernel", "apm_count_buffer",
-    "apm_count_file", "apm_count_shard_device", "apm_shard_range", "apm_synth_fill_device",
+    "apm_count_file", "apm_find_buffer", "apm_count_shard_device", "apm_shard_range", "apm_synth_fill_device",
     "apm_synth_fill_host", "apm_count_synthetic", "apm_set_timing", "apm_get_timing", "apm_pattern_kernel",
     "apm_device_alloc", "apm_device_free", "apm_device_upload", "apm_device_download",
     "apm_device_memset", "apm_synchronize",
@@ -79,6 +79,7 @@ def load_library():
         "apm_set_kernel": (i32, [vp, i32]),
         "apm_count_buffer": (i32, [vp, vp, u64, c.POINTER(u64)]),
         "apm_count_file": (i32, [vp, c.c_char_p, c.POINTER(u64)]),
+        "apm_find_buffer": (i32, [vp, vp, u64, i32, c.POINTER(u64), u64, c.POINTER(u64)]),
         "apm_count_shard_device": (i32, [vp, vp, u64, u64, u64, u64, u64, vp]),
         "apm_shard_range": (i32, [u64, i32, i32, i32, c.POINTER(u64), c.POINTER(u64)]),
         "apm_synth_fill_device": (i32, [vp, vp, u64, u64, u64]),
@@ -187,6 +188,17 @@ class ApmContext:
         ptr = ctypes.cast(buf, ctypes.c_void_p) if text else ctypes.c_void_p()
         self._check(self._lib.apm_count_buffer(self._ctx, ptr, len(text), out))
         return list(out)[: self.n_patterns]
+
+    def find_buffer(self, text, pattern_index, capacity=1 << 16):
+        """(positions ascending, total matches) of one pattern of the current set"""
+        text = bytes(text)
+        out = (ctypes.c_uint64 * max(capacity, 1))()
+        found = ctypes.c_uint64()
+        buf = ctypes.create_string_buffer(text, len(text)) if text else None
+        ptr = ctypes.cast(buf, ctypes.c_void_p) if text else ctypes.c_void_p()
+        self._check(self._lib.apm_find_buffer(self._ctx, ptr, len(text), pattern_index, out, capacity,
+                                              ctypes.byref(found)))
+        return list(out)[: min(found.value, capacity)], found.value
 
     def count_file(self, path):
         out = (ctypes.c_uint64 * max(self.n_patterns, 1))()

@@ -18,6 +18,14 @@
 #define APM_BANDED_MAX_K 7
 #define APM_BANDED_MAX_PATS 64
 
+/* Optional sink for match positions (apm_find_buffer): single-pattern launches only. */
+struct ApmPosSink {
+    unsigned long long *out;    /* device: global start offsets of matching windows (unordered), or NULL */
+    unsigned long long *count;  /* device: number of matches pushed (may exceed cap) */
+    unsigned long long cap;
+    unsigned long long text_off;/* global position of text[0] */
+};
+
 /* One pattern as a scan kernel sees it. */
 struct ApmPatDesc {
     uint32_t m;         /* length in bytes */
@@ -47,6 +55,7 @@ struct ApmScanArgs {
     int halo;              /* m_max - 1 of this launch */
     int table_words;       /* BITPAR: total uint32 in tables */
     int bytes_len;         /* bytes in the pattern pool */
+    ApmPosSink pos;
 };
 
 struct ApmGenericArgs {
@@ -61,6 +70,7 @@ struct ApmGenericArgs {
     int col_stride;        /* m_max + 1 */
     uint16_t *scratch;     /* n_pats * col_stride * (gridDim.x*256) uint16, lane-interleaved */
     unsigned long long *counts;
+    ApmPosSink pos;
 };
 
 struct ApmTailArgs {       /* truncated tail windows of patterns with m <= 128 */
@@ -70,6 +80,7 @@ struct ApmTailArgs {       /* truncated tail windows of patterns with m <= 128 *
     const uint8_t *bytes;
     unsigned long long *counts;
     int k;
+    ApmPosSink pos;
 };
 
 /* BANDED (filter + verify) launch.  A key is a KL-byte sub-block of one of the k+1 disjoint

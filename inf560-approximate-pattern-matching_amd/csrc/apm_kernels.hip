@@ -39,6 +39,12 @@ __device__ __forceinline__ uint32_t apm_wave_count(bool pred) {
 
 __device__ __forceinline__ int apm_min3(int a, int b, int c) { return min(min(a, b), c); }
 
+// match-position sink (apm_find_buffer): rare, unordered; the host sorts
+__device__ __forceinline__ void apm_push_pos(const ApmPosSink &ps, int64_t j_rel) {
+    const unsigned long long idx = atomicAdd(ps.count, 1ull);
+    if (idx < ps.cap) ps.out[idx] = ps.text_off + (unsigned long long)j_rel;
+}
+
 // lane l receives lane (l-1)'s value; lane 0 keeps `self` (DPP wave_shr:1, 1 VALU op)
 __device__ __forceinline__ int apm_shift_up1(int v) {
     return __builtin_amdgcn_update_dpp(v, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
@@ -100,13 +106,16 @@ __device__ __forceinline__ int bp_window(const uint8_t *s_tile, int joff, const 
 
 template <int W, int STRIDE>
 __device__ __forceinline__ uint32_t bp_scan(const uint8_t *s_tile, const uint32_t *tab, int m, int k,
-                                            int64_t base, int64_t jb, int64_t je_p, int tile, int tid) {
+                                            int64_t base, int64_t jb, int64_t je_p, int tile, int tid,
+                                            const ApmPosSink &ps) {
     uint32_t cnt = 0;
     for (int it = 0; it < tile; it += APM_BLOCK) {
         const int joff = it + tid;
         const int64_t j = base + joff;
         const int dist = bp_window<W, STRIDE>(s_tile, joff, tab, m);
-        cnt += apm_wave_count(j >= jb && j < je_p && dist <= k);
+        const bool hit = j >= jb && j < je_p && dist <= k;
+        cnt += apm_wave_count(hit);
+        if (ps.out && hit) apm_push_pos(ps, j);
     }
     return cnt;
 }
@@ -147,10 +156,10 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_bitpar_kernel(ApmScanArgs a) {
         const uint32_t *tab = s_tab + d.aux_off;
         uint32_t cnt;
         switch (d.w) {
-        case 1: cnt = bp_scan<1, 1>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid); break;
-        case 2: cnt = bp_scan<2, 2>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid); break;
-        case 3: cnt = bp_scan<3, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid); break;
-        default: cnt = bp_scan<4, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid); break;
+        case 1: cnt = bp_scan<1, 1>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
+        case 2: cnt = bp_scan<2, 2>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
+        case 3: cnt = bp_scan<3, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
+        default: cnt = bp_scan<4, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
         }
         if (lane == 0 && cnt) atomicAdd(&s_cnt[p], cnt);
     }
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_generic_kernel(ApmGenericArgs a
                 }
             }
             hit = (int)col[(int64_t)size * nthreads] <= a.k;
+            if (a.pos.out && hit) apm_push_pos(a.pos, j);
         }
         cnt += apm_wave_count(hit);
     }
@@ -435,6 +445,7 @@ __device__ __forceinline__ void apm_tail_body(const ApmTailArgs &a, int pat_slot
             }
         }
         const bool hit = valid && bp_distance<4>(pv, mv, size, size) <= a.k;
+        if (a.pos.out && hit) apm_push_pos(a.pos, j);
         const uint32_t cnt = apm_wave_count(hit);
         if ((tid & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
     }

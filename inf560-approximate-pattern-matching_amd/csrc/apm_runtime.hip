@@ -99,6 +99,9 @@ struct DeviceState {
     unsigned long long *d_counts = nullptr;   // P
     uint16_t *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    unsigned long long *d_pos_out = nullptr;   // apm_find_buffer: match positions (cap entries) + 1 counter
+    unsigned long long *d_pos_count = nullptr;
+    unsigned long long pos_cap = 0;
     uint8_t *d_text = nullptr;
     size_t text_cap = 0;
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
@@ -135,6 +138,7 @@ struct apm_ctx {
     int m_max = 0; // over non-trivial patterns
     bool patterns_set = false;
     bool timing_on = true;   // hipEvent bracketing of every call (apm_set_timing)
+    bool find_active = false; // apm_find_buffer in progress: kernels also push match positions
     std::string err;
     apm_timing timing{};
     RcclApi rccl;
@@ -532,7 +536,7 @@ int ensure_scratch(apm_ctx *ctx, DeviceState &ds, size_t bytes) {
 // generic-kernel launch over a pattern group; mode 0 full windows, 1 tails only, 2 everything
 int launch_generic_group(apm_ctx *ctx, DeviceState &ds, const GenericGroup &g, const ApmPatDesc *d_descs,
                          int mode, const uint8_t *d_text, int64_t avail, int64_t jb, int64_t je, int64_t nrel,
-                         unsigned long long *d_counts) {
+                         unsigned long long *d_counts, const ApmPosSink &sink) {
     if (g.descs.empty() || je <= jb) return APM_OK;
     int64_t span = je - jb;
     if (mode == 1) span = std::min<int64_t>(span, g.m_max); // at most m-1 tail windows per pattern
@@ -557,6 +561,7 @@ int launch_generic_group(apm_ctx *ctx, DeviceState &ds, const GenericGroup &g, c
     a.col_stride = (int)col;
     a.scratch = ds.d_scratch;
     a.counts = d_counts;
+    a.pos = sink;
     HIP_TRY(ctx, apm_launch_generic(a, (int)nbx, (int)g.descs.size(), ds.stream));
     ds.launches++;
     return APM_OK;
@@ -584,6 +589,14 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     // any): they ride as extra workgroups of the first BANDED launch, else get their own small launch
     ApmTailArgs ta{};
     bool tails_pending = !ctx->stails.descs.empty() && nrel - (int64_t)ctx->stails.m_max + 1 < je;
+    ApmPosSink sink{};
+    if (ctx->find_active) {
+        sink.out = ds.d_pos_out;
+        sink.count = ds.d_pos_count;
+        sink.cap = ds.pos_cap;
+        sink.text_off = text_off;
+    }
+    ta.pos = sink;
     if (tails_pending) {
         ta.text = d_text;
         ta.jb = jb;
@@ -686,15 +699,16 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         a.halo = L.m_max - 1;
         a.table_words = (int)L.tables.size();
         a.bytes_len = (int)L.bytes.size();
+        a.pos = sink;
         if (L.kind == APM_KERNEL_BITPAR) HIP_TRY(ctx, apm_launch_bitpar(a, ds.stream));
         else HIP_TRY(ctx, apm_launch_wavefront(a, ds.stream));
         ds.launches++;
     }
-    int rc = launch_generic_group(ctx, ds, ctx->longs, ds.d_long_descs, 2, d_text, avail, jb, je, nrel, d_counts);
+    int rc = launch_generic_group(ctx, ds, ctx->longs, ds.d_long_descs, 2, d_text, avail, jb, je, nrel, d_counts, sink);
     if (rc) return rc;
     if (ctx->timing_on) HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
     if (!ctx->tails.descs.empty() && nrel - (int64_t)ctx->tails.m_max + 1 < je) {
-        rc = launch_generic_group(ctx, ds, ctx->tails, ds.d_tail_descs, 1, d_text, avail, jb, je, nrel, d_counts);
+        rc = launch_generic_group(ctx, ds, ctx->tails, ds.d_tail_descs, 1, d_text, avail, jb, je, nrel, d_counts, sink);
         if (rc) return rc;
     }
     if (tails_pending) {
@@ -1159,6 +1173,75 @@ int apm_count_file(apm_ctx *ctx, const char *path, uint64_t *counts) {
         if (stage[b]) hipHostFree(stage[b]);
     }
     close(fd);
+    return rc;
+}
+
+int apm_find_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, int pattern_index, uint64_t *positions,
+                    uint64_t capacity, uint64_t *n_found) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (!ctx->patterns_set) return fail(ctx, APM_ERR_STATE, "apm_set_patterns has not been called");
+    if (pattern_index < 0 || pattern_index >= (int)ctx->pats.size() || !n_found || (!positions && capacity) || (!text && n))
+        return fail(ctx, APM_ERR_INVALID, "bad argument to apm_find_buffer");
+    // run the one pattern through the full-DP kernels with a position sink, then restore the plan
+    const std::vector<PatternInfo> saved = ctx->pats;
+    const int saved_kernel = ctx->kernel;
+    const PatternInfo one = saved[(size_t)pattern_index];
+    auto restore = [&]() {
+        ctx->pats = saved;
+        ctx->kernel = saved_kernel;
+        ctx->find_active = false;
+        for (auto &ds : ctx->devs) {
+            hipSetDevice(ds.dev);
+            if (ds.d_pos_out) hipFree(ds.d_pos_out), ds.d_pos_out = nullptr;
+            if (ds.d_pos_count) hipFree(ds.d_pos_count), ds.d_pos_count = nullptr;
+        }
+        const std::string keep = ctx->err;
+        ctx->patterns_set = (build_plan(ctx) == APM_OK);
+        if (!keep.empty()) ctx->err = keep;
+    };
+    ctx->pats.assign(1, one);
+    ctx->kernel = one.m <= APM_BITPAR_MAX_M ? APM_KERNEL_BITPAR : APM_KERNEL_GENERIC;
+    int rc = build_plan(ctx);
+    if (rc) { restore(); return rc; }
+    for (auto &ds : ctx->devs) {
+        if (hipSetDevice(ds.dev) != hipSuccess ||
+            hipMalloc((void **)&ds.d_pos_out, (size_t)std::max<uint64_t>(capacity, 1) * 8) != hipSuccess ||
+            hipMalloc((void **)&ds.d_pos_count, 16) != hipSuccess || hipMemset(ds.d_pos_count, 0, 16) != hipSuccess) {
+            restore();
+            return fail(ctx, APM_ERR_NOMEM, "cannot allocate the position buffer (%llu entries)", (unsigned long long)capacity);
+        }
+        ds.pos_cap = capacity;
+    }
+    ctx->find_active = true;
+    ctx->err.clear();
+    uint64_t cnt1 = 0;
+    rc = apm_count_buffer(ctx, text, n, &cnt1);
+    std::vector<uint64_t> all;
+    uint64_t total = 0;
+    if (rc == APM_OK) {
+        for (auto &ds : ctx->devs) {
+            unsigned long long c = 0;
+            if (hipSetDevice(ds.dev) != hipSuccess || hipMemcpy(&c, ds.d_pos_count, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = fail(ctx, APM_ERR_HIP, "cannot read back the match positions");
+                break;
+            }
+            total += c;
+            const size_t take = (size_t)std::min<uint64_t>(c, capacity);
+            const size_t at = all.size();
+            all.resize(at + take);
+            if (take && hipMemcpy(all.data() + at, ds.d_pos_out, take * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = fail(ctx, APM_ERR_HIP, "cannot read back the match positions");
+                break;
+            }
+        }
+    }
+    if (rc == APM_OK) {
+        std::sort(all.begin(), all.end());
+        for (size_t i = 0; i < all.size() && i < capacity; ++i) positions[i] = all[i];
+        *n_found = total;
+        if (total != cnt1) rc = fail(ctx, APM_ERR_STATE, "position sink count %llu != match count %llu", (unsigned long long)total, (unsigned long long)cnt1);
+    }
+    restore();
     return rc;
 }
 

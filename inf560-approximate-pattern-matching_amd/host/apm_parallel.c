@@ -4,7 +4,7 @@
  *
  * Keeps the reference's process contract:
  *   apm_parallel <distance> <text_file> <pattern_1> ... <pattern_P>
- *                [DB_OVER_RANKS|PATTERNS_OVER_RANKS] [--gpus N] [--kernel NAME]
+ *                [DB_OVER_RANKS|PATTERNS_OVER_RANKS] [--gpus N] [--kernel NAME] [--positions]
  *   argv grammar + usage line        /root/reference/src/sequential.c:35-77
  *   optional trailing approach flag  /root/reference/src/main.c:66-86 (accepted, ignored:
  *                                    the text is always sharded over the GPUs)
@@ -37,6 +37,7 @@ int main(int argc, char **argv) {
     int n_gpus = 0; /* 0 = all visible */
     int kernel = APM_KERNEL_AUTO;
     int verbose = 0;
+    int want_positions = 0; /* extension: also print the matching offsets */
 
     /* strip our own options (anywhere after the pattern list starts is fine:
        the reference has none, so nothing is taken away from its grammar) */
@@ -52,6 +53,8 @@ int main(int argc, char **argv) {
             }
         } else if (!strcmp(argv[i], "--verbose")) {
             verbose = 1;
+        } else if (!strcmp(argv[i], "--positions")) {
+            want_positions = 1;
         } else {
             argv[w++] = argv[i];
         }
@@ -140,6 +143,45 @@ int main(int argc, char **argv) {
 
     for (int i = 0; i < nb_patterns; ++i)
         printf("Number of matches for pattern <%s>: %llu\n", argv[i + 3], (unsigned long long)n_matches[i]);
+
+    if (want_positions) { /* off by default: stdout stays identical to the reference */
+        FILE *f = fopen(filename, "rb");
+        uint8_t *buf = NULL;
+        uint64_t n = 0, cap = 0;
+        if (f) {
+            for (;;) {
+                if (n == cap) {
+                    cap = cap ? cap * 2 : ((uint64_t)1 << 20);
+                    uint8_t *nb = (uint8_t *)realloc(buf, (size_t)cap);
+                    if (!nb) { free(buf); buf = NULL; break; }
+                    buf = nb;
+                }
+                const size_t r = fread(buf + n, 1, (size_t)(cap - n), f);
+                if (!r) break;
+                n += r;
+            }
+            fclose(f);
+        }
+        if (!buf && n) {
+            fprintf(stderr, "Unable to allocate memory for the positions pass\n");
+            apm_destroy(ctx);
+            return 1;
+        }
+        const uint64_t pcap = (uint64_t)1 << 20;
+        uint64_t *pos = (uint64_t *)malloc((size_t)pcap * sizeof(uint64_t));
+        for (int i = 0; pos && i < nb_patterns; ++i) {
+            uint64_t found = 0;
+            if (apm_find_buffer(ctx, buf, n, i, pos, pcap, &found) != APM_OK) {
+                fprintf(stderr, "%s\n", apm_last_error(ctx));
+                break;
+            }
+            printf("Positions for pattern <%s>:", argv[i + 3]);
+            for (uint64_t q = 0; q < found && q < pcap; ++q) printf(" %llu", (unsigned long long)pos[q]);
+            printf(found > pcap ? " ...\n" : "\n");
+        }
+        free(pos);
+        free(buf);
+    }
 
     apm_destroy(ctx);
     free(len);

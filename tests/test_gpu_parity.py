@@ -501,3 +501,46 @@ def test_wide_bands(ctx, apm, k):
     assert sum(want) >= 3
     for variant in ("auto", "banded", "wavefront"):
         assert _run(ctx, apm, variant, pats, k, text) == want, variant
+
+
+# ---------------------------------------------------------------- match positions
+def _oracle_positions(text, p, k):
+    n, m = len(text), len(p)
+    out = []
+    for j in range(0, max(0, n - k)):
+        size = min(m, n - j)
+        if H.window_distance(p[:size], text[j:j + size]) <= k:
+            out.append(j)
+    return out
+
+
+def test_find_positions_equal_oracle(ctx, apm):
+    rnd = random.Random(31)
+    text = bytes(rnd.choice(b"ACGT") for _ in range(3000)) + b"ACGTACGTAC"
+    pats = [text[100:132], text[500:516], b"ACGTACGTACGT", text[1000:1200], b"GG"]
+    for k in (0, 2, 3):
+        ctx.set_kernel("auto")
+        ctx.set_patterns(pats, k)
+        counts = ctx.count_buffer(text)
+        for i, p in enumerate(pats):
+            want = _oracle_positions(text, p, k)
+            got, total = ctx.find_buffer(text, i, capacity=8192)
+            assert total == len(want) == counts[i]
+            assert got == want
+        assert ctx.count_buffer(text) == counts          # the pattern set survived the find calls
+    got, total = ctx.find_buffer(text, 4, capacity=3)     # capacity smaller than the number of matches
+    assert total == counts[4] and len(got) == 3 and set(got) <= set(_oracle_positions(text, pats[4], 3))
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="host/apm_parallel not built")
+def test_cli_positions_flag():
+    c = next(c for c in CASES if c["name"] == "chrY_k2")
+    text = H.case_text(c)
+    r = _cli([str(c["k"]), c["path"]] + [p.decode() for p in c["patterns"]] + ["--positions"])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.decode().splitlines()
+    pos_lines = [l for l in lines if l.startswith("Positions for pattern")]
+    assert len(pos_lines) == len(c["patterns"])
+    for l, p, cnt in zip(pos_lines, c["patterns"], c["counts"]):
+        got = [int(x) for x in l.split(">:", 1)[1].split()]
+        assert len(got) == cnt and got == _oracle_positions(text, p, c["k"])
