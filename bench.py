@@ -249,6 +249,9 @@ def main():
         "config": {"workload": "%s: %s" % (args.config, cfg["desc"]), "text_bytes_total": n_total,
                    "text_bytes_per_gpu": per_gpu, "patterns": P, "pattern_len": sorted(set(lens)), "k": k,
                    "kernel": "+".join(kernel_names), "partition": "text-sharded x%d, halo m_max-1, RCCL all-reduce of counts" % world},
+        "note": "value = algorithmic window-DP cells (sum_p (n-k)*m_p^2) per second with bit-exact counts; "
+                "config.kernel names the kernel that produced it ('banded' = exact shortcut: pigeonhole key filter + "
+                "banded verification, it does NOT evaluate every DP cell); raw full-DP throughput is under variants",
         "positions_x_patterns_per_s": float(max(0, n_total - k)) * P / (elapsed / args.steps),
         "counts": final_counts,
         "counts_exact_vs_planted": bool(counts_ok),
