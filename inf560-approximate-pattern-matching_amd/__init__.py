@@ -16,7 +16,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapm_hip.so")
+LIB_PATH = os.environ.get("APM_LIB_PATH") or os.path.join(_HERE, "libapm_hip.so")  # APM_LIB_PATH: A/B builds
 
 APM_KERNEL_AUTO, APM_KERNEL_GENERIC, APM_KERNEL_WAVEFRONT, APM_KERNEL_BITPAR, APM_KERNEL_BANDED = range(5)
 KERNEL_NAMES = {0: "auto", 1: "generic", 2: "wavefront", 3: "bitpar", 4: "banded"}

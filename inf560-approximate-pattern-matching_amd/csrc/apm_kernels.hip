@@ -901,49 +901,51 @@ void apm_filter_kernel(ApmFilterArgs a) {
         const int p0 = tid * 16; // LDS offset of this lane's first position
         uint32_t *queue = s_queue + qa * a.qcap;
 
-        // ---- fingerprints of this lane's sampled positions ----
-        constexpr int NF = 16 / STRIDE;
-        uint32_t f[NF];
-        {
-            const uint4 va = *reinterpret_cast<const uint4 *>(s_tile + p0);
-            if constexpr (STRIDE == 16) {
-                f[0] = apm_fp16(apm_fp8(va.x, va.y), apm_fp8(va.z, va.w));
-            } else if constexpr (STRIDE == 8) {
-                f[0] = apm_fp8(va.x, va.y);
-                f[1] = apm_fp8(va.z, va.w);
-            } else { // every position: KL = 8, 6 or 4 key bytes
-                const uint2 vb = *reinterpret_cast<const uint2 *>(s_tile + p0 + 16);
-                const uint32_t w[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
-                constexpr int NK0 = KL > 4 ? 20 : 16;
-                uint32_t k0[NK0];
-#pragma unroll
-                for (int i = 0; i < NK0; ++i)
-                    k0[i] = (i & 3) ? __builtin_amdgcn_alignbyte(w[i / 4 + 1], w[i / 4], (uint32_t)(i & 3)) : w[i / 4];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if constexpr (KL > 4) f[i] = apm_fp8(k0[i], k0[i + 4] & apm_hi_mask<KL>());
-                    else f[i] = k0[i];
-                }
+        auto probe = [&](uint32_t fi, int pos) __attribute__((always_inline)) { // one hash-table probe
+            const uint32_t h = apm_table_hash<KL>(fi);
+            const uint32_t slot = h >> hshift;
+            const uint32_t tag = h & 0xffffu;
+            const uint32_t rep = tag | (tag << 16);
+            const uint4 tg = s_tab[slot]; // 8 x 16-bit tags
+            const u16x2 m01 = __builtin_elementwise_min(apm_as_u16x2(tg.x ^ rep), apm_as_u16x2(tg.y ^ rep));
+            const u16x2 m23 = __builtin_elementwise_min(apm_as_u16x2(tg.z ^ rep), apm_as_u16x2(tg.w ^ rep));
+            const u16x2 mm = __builtin_elementwise_min(m01, m23); // v_pk_min_u16: a zero half = tag match
+            bool hit = (mm.x == 0) | (mm.y == 0);
+            for (int o = 0; o < a.n_ovf; ++o) hit |= (s_ovf[2 * o] == tag);
+            if (hit) { // rare with long keys: defer the bucket walk to the cooperative phase
+                const uint32_t idx = atomicAdd(&s_qn[qc], 1u);
+                if (idx < (uint32_t)a.qcap) queue[idx] = (tag << 16) | (uint32_t)pos;
             }
-        }
-
-        // ---- filter + enqueue: one hash-table probe per sampled position ----
-        if (!(a.ablate & 1)) {
+        };
+        if (a.ablate & 1) return; // measurement aid: skip the probes
+        const uint4 va = *reinterpret_cast<const uint4 *>(s_tile + p0);
+        if constexpr (STRIDE == 16) {
+            probe(apm_fp16(apm_fp8(va.x, va.y), apm_fp8(va.z, va.w)), p0);
+        } else if constexpr (STRIDE == 8) {
+            probe(apm_fp8(va.x, va.y), p0);
+            probe(apm_fp8(va.z, va.w), p0 + 8);
+        } else { // every position (KL = 8, 6 or 4 key bytes): four groups of four probes in a runtime
+                 // loop -- few live registers, so more waves fit a SIMD (these classes are latency bound)
+            const uint2 vb = *reinterpret_cast<const uint2 *>(s_tile + p0 + 16);
+            const uint32_t w[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {
+                uint32_t wa, wb, wc; // the three dwords covering positions 4g .. 4g+3 (+ 8 key bytes)
+                switch (g) {
+                case 0: wa = w[0]; wb = w[1]; wc = w[2]; break;
+                case 1: wa = w[1]; wb = w[2]; wc = w[3]; break;
+                case 2: wa = w[2]; wb = w[3]; wc = w[4]; break;
+                default: wa = w[3]; wb = w[4]; wc = w[5]; break;
+                }
 #pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                const uint32_t h = apm_table_hash<KL>(f[i]);
-                const uint32_t slot = h >> hshift;
-                const uint32_t tag = h & 0xffffu;
-                const uint32_t rep = tag | (tag << 16);
-                const uint4 tg = s_tab[slot]; // 8 x 16-bit tags
-                const u16x2 m01 = __builtin_elementwise_min(apm_as_u16x2(tg.x ^ rep), apm_as_u16x2(tg.y ^ rep));
-                const u16x2 m23 = __builtin_elementwise_min(apm_as_u16x2(tg.z ^ rep), apm_as_u16x2(tg.w ^ rep));
-                const u16x2 mm = __builtin_elementwise_min(m01, m23); // v_pk_min_u16: a zero half = tag match
-                bool hit = (mm.x == 0) | (mm.y == 0);
-                for (int o = 0; o < a.n_ovf; ++o) hit |= (s_ovf[2 * o] == tag);
-                if (hit) { // rare with long keys: defer the bucket walk to the cooperative phase
-                    const uint32_t idx = atomicAdd(&s_qn[qc], 1u);
-                    if (idx < (uint32_t)a.qcap) queue[idx] = (tag << 16) | (uint32_t)(p0 + i * STRIDE);
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t lo = i ? __builtin_amdgcn_alignbyte(wb, wa, (uint32_t)i) : wa;
+                    uint32_t fi = lo;
+                    if constexpr (KL > 4) {
+                        const uint32_t hi = i ? __builtin_amdgcn_alignbyte(wc, wb, (uint32_t)i) : wb;
+                        fi = apm_fp8(lo, hi & apm_hi_mask<KL>());
+                    }
+                    probe(fi, p0 + 4 * g + i);
                 }
             }
         }

@@ -639,6 +639,10 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.lg_nb = L.lg_nb;
             f.n_ovf = (int)(L.ovf.size() / 2);
             f.qcap = L.qcap;
+            if (L.stride == 1) { // measurement aid: APM_QCAP_S1 overrides the per-tile candidate queue of the per-position classes
+                static const int q_env = getenv("APM_QCAP_S1") ? atoi(getenv("APM_QCAP_S1")) : 0;
+                if (q_env >= 64 && q_env <= 8192) f.qcap = q_env;
+            }
             f.key_len = L.key_len;
             f.stride = L.stride;
             f.counts = d_counts;
@@ -677,7 +681,11 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 f.tail = ta;
                 tails_pending = false;
             }
-            HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * L.blocks_per_cu[f.use_dma], ds.stream));
+            {
+                static const int bpc_env = getenv("APM_BPC_CAP") ? atoi(getenv("APM_BPC_CAP")) : 0; // measurement aid
+                const int bpc = bpc_env > 0 ? std::min(bpc_env, L.blocks_per_cu[f.use_dma]) : L.blocks_per_cu[f.use_dma];
+                HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * bpc, ds.stream));
+            }
             ds.launches++;
             continue;
         }

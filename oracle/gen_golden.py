@@ -45,6 +45,26 @@ def run_ref(k, text_path, patterns):
     return counts
 
 
+def write_stdout_fixtures():
+    """tests/golden/expected/*.txt: the `Number of matches` lines the reference prints for the
+    invocations of its own batch scripts (scripts/basic_test.batch:10, scripts/run_tests:31,56) --
+    what scripts/run_tests.sh diffs the GPU CLI against."""
+    out_dir = os.path.join(GOLD, "expected")
+    os.makedirs(out_dir, exist_ok=True)
+    L = {n: read("line_%s.fa" % n).split()[0] for n in ("10", "20", "20783", "non_existent")}
+    runs = {
+        "basic_test": ("small_chrY_x100.fa", [L["non_existent"]] + [L["20783"]] * 5),
+        "easy": ("easy.fa", ["123", "456", "78934"]),
+        "complex": ("small_chrY_x100.fa", [L["10"], L["20"], L["non_existent"]] * 2),
+    }
+    for name, (fn, pats) in runs.items():
+        r = subprocess.run([REF_BIN, "0", os.path.join(DNA, fn)] + pats, capture_output=True, check=True)
+        lines = [l for l in r.stdout.decode("latin-1").splitlines() if l.startswith("Number of matches")]
+        with open(os.path.join(out_dir, name + ".txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    print("wrote %d stdout fixtures" % len(runs))
+
+
 def read(name):
     with open(os.path.join(DNA, name), "rb") as f:
         return f.read().decode("latin-1")
@@ -195,4 +215,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--stdout-fixtures" in sys.argv:  # only the small text fixtures, golden.json untouched
+        write_stdout_fixtures()
+    else:
+        main()
+        write_stdout_fixtures()

@@ -333,6 +333,15 @@ def test_cli_matches_reference_stdout():
 
 
 @pytest.mark.skipif(not os.path.exists(CLI), reason="host/apm_parallel not built")
+def test_batch_runner_script():
+    """scripts/run_tests.sh = the reference's scripts/basic_test.batch + scripts/run_tests invocations,
+    diffing the result lines against fixtures written from the reference binary."""
+    r = subprocess.run(["bash", os.path.join(H.ROOT, "scripts", "run_tests.sh"), "1"], capture_output=True)
+    assert r.returncode == 0, r.stdout.decode() + r.stderr.decode()
+    assert r.stdout.decode().count("result OK") == 5
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="host/apm_parallel not built")
 def test_cli_error_paths_match_reference():
     errs = H.golden()["cli_errors"]
     dna = os.path.join(H.GOLDEN_DIR, "dna")

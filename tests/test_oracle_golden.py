@@ -34,6 +34,23 @@ def test_readme_published_counts():
     assert [len(p) for p in c["patterns"]] == [32, 50, 50, 50, 50, 50]
 
 
+@pytest.mark.parametrize("name,fn", [("basic_test", "small_chrY_x100.fa"), ("easy", "easy.fa"),
+                                     ("complex", "small_chrY_x100.fa")])
+def test_batch_script_fixtures(name, fn):
+    """tests/golden/expected/*.txt (the reference binary's result lines for the invocations of its
+    scripts/basic_test.batch:10 and scripts/run_tests:31,56) == the oracle (banded, multi-threaded)."""
+    with open(os.path.join(H.GOLDEN_DIR, "dna", fn), "rb") as f:
+        text = f.read()
+    pats, want = [], []
+    with open(os.path.join(H.GOLDEN_DIR, "expected", name + ".txt"), "rb") as f:
+        for line in f.read().splitlines():
+            head, cnt = line.rsplit(b">: ", 1)
+            pats.append(head[len(b"Number of matches for pattern <"):])
+            want.append(int(cnt))
+    assert len(pats) in (3, 6)
+    assert H.oracle_counts(text, pats, 0, banded=True) == want
+
+
 def test_single_thread_equals_multi_thread():
     c = next(c for c in CASES if c["name"] == "chrY_k3")
     text = H.case_text(c)
