@@ -532,7 +532,7 @@ __device__ __forceinline__ void apm_lds_dwords(const uint8_t *base, int off, uin
 // mask of the key bytes living in the second dword of an (up to) 8-byte key
 template <int KL>
 __device__ __forceinline__ constexpr uint32_t apm_hi_mask() {
-    return KL >= 8 ? 0xffffffffu : (KL <= 4 ? 0u : ((1u << (8 * (KL - 4))) - 1u));
+    return KL >= 8 ? 0xffffffffu : (KL <= 4 ? 0u : ((1u << (8 * ((KL - 4) & 3))) - 1u));
 }
 
 template <int KL>
@@ -731,7 +731,7 @@ __device__ __forceinline__ bool apm_ext_bwd(const uint8_t *tb, int te, const uin
 // tile buffers, waits placed by hand (vmcnt(1): the younger tile stays in flight).  Needs a 16-byte
 // aligned text pointer.  DMA = 0: register-staged buffer loads, two LDS buffers, compiler-placed waits.
 template <int BAND, int KL, int STRIDE, int DMA>
-__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : 6))
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : ((BAND >= 1 && STRIDE == 1) ? 5 : 6)))
 void apm_filter_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -752,6 +752,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
     uint2 *s_pinfo = reinterpret_cast<uint2 *>(s_img + a.o_pinfo);       // n_pats: {byte_off | m<<16, aux_off}
     const uint16_t *s_next = reinterpret_cast<const uint16_t *>(s_img + a.o_next); // nk: chain links (id+1, 0 = end)
     const uint16_t *s_poff = reinterpret_cast<const uint16_t *>(s_img + a.o_poff); // piece offsets a_q
+    const uint8_t *s_bmp = s_img + a.o_bmp;                                        // per-position classes: key bitmap
     uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_img + a.image_len); // 2 x qcap
     uint32_t *s_cnt = s_queue + 2 * a.qcap;
     uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [2] queue counters
@@ -924,29 +925,36 @@ void apm_filter_kernel(ApmFilterArgs a) {
         } else if constexpr (STRIDE == 8) {
             probe(apm_fp8(va.x, va.y), p0);
             probe(apm_fp8(va.z, va.w), p0 + 8);
-        } else { // every position (KL = 8, 6 or 4 key bytes): four groups of four probes in a runtime
-                 // loop -- few live registers, so more waves fit a SIMD (these classes are latency bound)
+        } else {
+            // every position (KL = 8, 6 or 4 key bytes).  First level = a presence bitmap over the 2-bit byte
+            // codes (b >> code_shift) & 3: the lane packs the codes of its 24 bytes into 48 bits once, the
+            // key code word of position i is a 2i-bit funnel shift of them, and its bit sits in byte
+            // x & (NB-1) of the bitmap (ds_read_u8), bit x >> log2(NB).  ~6 instructions per position instead
+            // of a fingerprint + bucket probe; the bucket walk happens in the cooperative phase for the hits.
             const uint2 vb = *reinterpret_cast<const uint2 *>(s_tile + p0 + 16);
             const uint32_t w[6] = {va.x, va.y, va.z, va.w, vb.x, vb.y};
-#pragma unroll 1
-            for (int g = 0; g < 4; ++g) {
-                uint32_t wa, wb, wc; // the three dwords covering positions 4g .. 4g+3 (+ 8 key bytes)
-                switch (g) {
-                case 0: wa = w[0]; wb = w[1]; wc = w[2]; break;
-                case 1: wa = w[1]; wb = w[2]; wc = w[3]; break;
-                case 2: wa = w[2]; wb = w[3]; wc = w[4]; break;
-                default: wa = w[3]; wb = w[4]; wc = w[5]; break;
-                }
+            uint32_t pk[6];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t lo = i ? __builtin_amdgcn_alignbyte(wb, wa, (uint32_t)i) : wa;
-                    uint32_t fi = lo;
-                    if constexpr (KL > 4) {
-                        const uint32_t hi = i ? __builtin_amdgcn_alignbyte(wc, wb, (uint32_t)i) : wb;
-                        fi = apm_fp8(lo, hi & apm_hi_mask<KL>());
-                    }
-                    probe(fi, p0 + 4 * g + i);
-                }
+            for (int i = 0; i < 6; ++i) {
+                const uint32_t c = (w[i] >> a.code_shift) & 0x03030303u;
+                const uint32_t u = c | (c >> 6);
+                pk[i] = (u | (u >> 12)) & 0xffu;
+            }
+            const uint32_t clo = pk[0] | (pk[1] << 8) | (pk[2] << 16) | (pk[3] << 24);
+            const uint32_t chi = pk[4] | (pk[5] << 8);
+            constexpr int LB = 2 * KL - 3; // log2 of the bitmap's byte count
+            uint32_t hits = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t x = i ? __builtin_amdgcn_alignbit(chi, clo, 2u * (uint32_t)i) : clo;
+                const uint32_t byte = s_bmp[x & ((1u << LB) - 1u)];
+                hits |= ((byte >> ((x >> LB) & 7u)) & 1u) << i;
+            }
+            while (hits) {
+                const int i = __builtin_ctz(hits);
+                hits &= hits - 1u;
+                const uint32_t idx = atomicAdd(&s_qn[qc], 1u);
+                if (idx < (uint32_t)a.qcap) queue[idx] = (uint32_t)(p0 + i);
             }
         }
     };
@@ -970,7 +978,9 @@ void apm_filter_kernel(ApmFilterArgs a) {
             if constexpr (KL == 16) fi = apm_fp16(apm_fp8(fw[0], fw[1]), apm_fp8(fw[2], fw[3]));
             else if constexpr (KL > 4) fi = apm_fp8(fw[0], fw[1] & apm_hi_mask<KL>());
             else fi = fw[0];
-            const uint32_t slot = apm_table_hash<KL>(fi) >> hshift;
+            const uint32_t hh = apm_table_hash<KL>(fi);
+            const uint32_t slot = hh >> hshift;
+            if constexpr (STRIDE == 1) tag = hh & 0xffffu; // (the bitmap filter queues bare positions)
             const uint16_t *tag16 = reinterpret_cast<const uint16_t *>(s_tab + slot);
             const uint16_t *kid16p = reinterpret_cast<const uint16_t *>(s_kid + slot);
             // Find this lane's matching way first (one 16-byte read of the tags, one of the key ids), THEN
@@ -1160,7 +1170,7 @@ __device__ __forceinline__ bool apm_ext_bwd_g(const uint8_t *text, int64_t limit
 }
 
 template <int BAND, int KL, int STRIDE>
-__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 3 || STRIDE == 1) ? 4 : 5))
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 7 : ((BAND >= 2 || STRIDE == 1) ? 4 : 5))
 void apm_stream_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1172,8 +1182,8 @@ void apm_stream_kernel(ApmFilterArgs a) {
     constexpr int NF = 16 / STRIDE;
     constexpr int NSH = 2 * BAND + 1;
     constexpr bool PAIRS = (STRIDE == 1) && (BAND >= 1);
-    constexpr int GRP = NF < 4 ? NF : 4;    // probes between two flush checks
-    constexpr int QW = 64 * GRP + 64;       // wave queue entries: flushed as soon as it holds >= 64
+    constexpr int GRP = STRIDE == 1 ? 4 : 4 * NF; // probes between two flush checks (sampled classes: 4 chunks)
+    constexpr int QW = 64 * GRP + 64;             // wave queue entries: flushed as soon as it holds >= 64
     uint8_t *s_img = smem;
     uint8_t *s_pat = s_img;
     const uint4 *s_tab = reinterpret_cast<const uint4 *>(s_img + a.o_tab);
@@ -1380,13 +1390,11 @@ void apm_stream_kernel(ApmFilterArgs a) {
     auto process = [&](const u32x4 &v, const uint2 &e, int64_t cc) __attribute__((always_inline)) {
         const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
         const bool valid = cc < nch && !(a.ablate & 1);
-        if constexpr (STRIDE == 16) {
+        if constexpr (STRIDE == 16) { // (sampled classes: the caller drains once per four chunks)
             probe(apm_fp16(apm_fp8(v.x, v.y), apm_fp8(v.z, v.w)), pos, valid);
-            drain();
         } else if constexpr (STRIDE == 8) {
             probe(apm_fp8(v.x, v.y), pos, valid);
             probe(apm_fp8(v.z, v.w), pos + 8, valid);
-            drain();
         } else { // every position, KL = 8, 6 or 4 key bytes: four groups of four probes, ONE drain site
             const uint32_t w[6] = {v.x, v.y, v.z, v.w, e.x, e.y};
 #pragma unroll 1
@@ -1438,6 +1446,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
             { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 5 * W, r1, e1); process(v, e, c + W); }
             { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 6 * W, r2, e2); process(v, e, c + 2 * W); }
             { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 7 * W, r3, e3); process(v, e, c + 3 * W); }
+            drain(); // ONE verification site: keeps the loop small and its uniform state in SGPRs
         }
     }
     flush(qcount);
@@ -1451,7 +1460,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
 
 static size_t apm_stream_lds_bytes(const ApmFilterArgs &a) {
     const int nf = 16 / a.stride;
-    const size_t qw = (size_t)(64 * (nf < 4 ? nf : 4) + 64);
+    const size_t qw = (size_t)(64 * (a.stride == 1 ? 4 : 4 * nf) + 64);
     size_t b = (size_t)a.image_len + 4 * qw * 8 + (size_t)((a.n_pats + 3) & ~3) * 4 + 16;
     return b < 4608 ? 4608 : b; // the tail workgroups need 256 uint4 + 128 bytes
 }

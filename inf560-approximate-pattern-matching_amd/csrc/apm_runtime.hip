@@ -66,6 +66,7 @@ struct TiledLaunch {       // host description of one tiled scan launch
     std::vector<uint32_t> pinfo;      // BANDED: per pattern {byte_off | m<<16, aux_off}
     std::vector<uint8_t> image;       // BANDED: LDS image (bytes | table | kids | ovf | kinfo | pinfo)
     int o_tab = 0, o_kid = 0, o_ovf = 0, o_kinfo = 0, o_pinfo = 0, o_next = 0, o_poff = 0;
+    int o_bmp = 0, code_shift = 1; // per-position classes: key bitmap over 2-bit byte codes
     int key_len = 0, stride = 0;      // BANDED: (16,16), (8,8) or (8,1)
     int nb = 0, lg_nb = 0, qcap = 0;
     int a_max = 0;                    // BANDED: largest key offset
@@ -492,6 +493,30 @@ int build_plan(apm_ctx *ctx) {
             for (const ApmKey &kk : L.keys) nxt.push_back(kk.next);
             L.o_next = append(nxt.data(), nxt.size() * 2);
             L.o_poff = append(L.piece_off.data(), L.piece_off.size() * 2);
+            if (stride == 1) {
+                // First-level filter of the per-position classes: a presence bitmap indexed by the 2-bit
+                // codes (b >> s) & 3 of the key bytes.  s is picked to spread this launch's pattern bytes
+                // over the four codes as evenly as possible (s = 1 separates A,C,G,T and a,c,g,t exactly).
+                long best = -1;
+                for (int sft = 0; sft < 7; ++sft) {
+                    long hist[4] = {0, 0, 0, 0};
+                    for (const ApmPatDesc &dd : L.descs)
+                        for (uint32_t y = 0; y < dd.m; ++y) ++hist[(L.bytes[dd.byte_off + y] >> sft) & 3];
+                    const long score = std::min(std::min(hist[0], hist[1]), std::min(hist[2], hist[3])) * 4 +
+                                       (hist[0] > 0) + (hist[1] > 0) + (hist[2] > 0) + (hist[3] > 0) + (sft == 1);
+                    if (score > best) { best = score; L.code_shift = sft; }
+                }
+                const uint32_t nbytes = 1u << (2 * klen - 3);
+                std::vector<uint8_t> bmp(nbytes, 0);
+                for (const ApmKey &kk : L.keys) {
+                    const ApmPatDesc &dd = L.descs[kk.pat];
+                    uint32_t x = 0;
+                    for (int z = 0; z < klen; ++z)
+                        x |= (uint32_t)((L.bytes[dd.byte_off + kk.off + z] >> L.code_shift) & 3) << (2 * z);
+                    bmp[x & (nbytes - 1)] |= (uint8_t)(1u << (x >> (2 * klen - 3)));
+                }
+                L.o_bmp = append(bmp.data(), bmp.size());
+            }
             ctx->tiled.push_back(std::move(L));
         }
     }
@@ -634,6 +659,8 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.o_pinfo = L.o_pinfo;
             f.o_next = L.o_next;
             f.o_poff = L.o_poff;
+            f.o_bmp = L.o_bmp;
+            f.code_shift = L.code_shift;
             f.nk = (int)L.keys.size();
             f.nb = L.nb;
             f.lg_nb = L.lg_nb;

@@ -85,3 +85,20 @@ def test_bitvector_core_on_host(tmp_path):
                     src, os.path.join(H.ROOT, "oracle", "apm_oracle.c"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_no_kernel_spills_to_scratch():
+    """csrc/apm_kernels.resources.txt (written by the Makefile from the compiler's resource-usage
+    remarks): a spill reload inside a streaming loop is a vector-memory op that drains every prefetch
+    queued behind it (vmcnt counts in order) -- it cost 10 % on the headline kernel once."""
+    path = os.path.join(H.PKG_DIR, "csrc", "apm_kernels.resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("library was not built by the Makefile in this checkout")
+    name, seen = None, 0
+    for line in open(path):
+        if line.startswith("Function Name:"):
+            name = line.split(":", 1)[1].strip()
+        elif line.startswith("ScratchSize"):
+            seen += 1
+            assert int(line.rsplit(":", 1)[1]) == 0, "%s spills to scratch" % name
+    assert seen >= 40
