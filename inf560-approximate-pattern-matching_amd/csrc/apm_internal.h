@@ -110,6 +110,7 @@ struct ApmFilterArgs {
                               o_kinfo: nk x (pat | off<<12 | piece<<21); o_pinfo: n_pats x {byte_off | m<<16, aux_off} */
     int image_len, o_tab, o_kid, o_ovf, o_kinfo, o_pinfo, o_next, o_poff; /* o_next: nk x u16 chain links,
                               o_poff: piece offsets a_q (u16), per pattern contiguous */
+    int o_pat;             /* pattern bytes inside the image (0 unless a bitmap leads the image) */
     int o_bmp, code_shift; /* per-position classes: key presence bitmap over the 2-bit byte codes
                               (b >> code_shift) & 3 of the key_len key bytes (2^(2*key_len) bits); bit of code
                               word x lives in byte x & (NB-1), bit x >> log2(NB), NB = 2^(2*key_len-3) */

@@ -730,8 +730,10 @@ __device__ __forceinline__ bool apm_ext_bwd(const uint8_t *tb, int te, const uin
 // DMA = 1: tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), three LDS
 // tile buffers, waits placed by hand (vmcnt(1): the younger tile stays in flight).  Needs a 16-byte
 // aligned text pointer.  DMA = 0: register-staged buffer loads, two LDS buffers, compiler-placed waits.
+typedef __attribute__((address_space(3))) uint8_t apm_lds_u8; // LDS byte, for constant-address accesses
+
 template <int BAND, int KL, int STRIDE, int DMA>
-__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : ((BAND >= 1 && STRIDE == 1) ? 5 : 6)))
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : ((BAND >= 1 && STRIDE == 1) ? (DMA ? 5 : 4) : 6)))
 void apm_filter_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -743,8 +745,8 @@ void apm_filter_kernel(ApmFilterArgs a) {
     constexpr int NBUF = DMA ? 3 : 2;
     uint8_t *s_tile0 = smem;
     uint8_t *s_tile1 = smem + a.tile_len;
-    uint8_t *s_img = smem + NBUF * a.tile_len;
-    uint8_t *s_pat = s_img;                                              // raw pattern bytes
+    uint8_t *s_img = smem + NBUF * APM_FILTER_POS;                       // (= a.tile_len, as a constant)
+    uint8_t *s_pat = s_img + a.o_pat;                                    // raw pattern bytes
     uint4 *s_tab = reinterpret_cast<uint4 *>(s_img + a.o_tab);           // nb buckets x 8 16-bit tags
     uint4 *s_kid = reinterpret_cast<uint4 *>(s_img + a.o_kid);           // nb x 8 16-bit key ids
     uint32_t *s_ovf = reinterpret_cast<uint32_t *>(s_img + a.o_ovf);     // n_ovf x {tag, kid16}
@@ -752,7 +754,6 @@ void apm_filter_kernel(ApmFilterArgs a) {
     uint2 *s_pinfo = reinterpret_cast<uint2 *>(s_img + a.o_pinfo);       // n_pats: {byte_off | m<<16, aux_off}
     const uint16_t *s_next = reinterpret_cast<const uint16_t *>(s_img + a.o_next); // nk: chain links (id+1, 0 = end)
     const uint16_t *s_poff = reinterpret_cast<const uint16_t *>(s_img + a.o_poff); // piece offsets a_q
-    const uint8_t *s_bmp = s_img + a.o_bmp;                                        // per-position classes: key bitmap
     uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_img + a.image_len); // 2 x qcap
     uint32_t *s_cnt = s_queue + 2 * a.qcap;
     uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [2] queue counters
@@ -761,8 +762,8 @@ void apm_filter_kernel(ApmFilterArgs a) {
     // the descriptor's num_records does the bounds check (out-of-range lanes return 0 and move no
     // data).  No other vector-memory operation lives in the tile loop, so the compiler's vmcnt
     // bookkeeping keeps the younger prefetch in flight while the older one is consumed.
-    auto fetch = [&](int64_t t, u32x4 &r0) __attribute__((always_inline)) {
-        const int64_t g = a.tile0 + t * a.tile_w - a.front; // >= -31
+    auto fetch = [&](int t, u32x4 &r0) __attribute__((always_inline)) {
+        const int64_t g = a.tile0 + (int64_t)t * a.tile_w - a.front; // >= -31
         const int64_t gb = g > 0 ? g : 0;
         const int64_t lim = a.avail_pad - gb;
         const uint32_t nrec = lim <= 0 ? 0u : (lim > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)lim);
@@ -775,8 +776,11 @@ void apm_filter_kernel(ApmFilterArgs a) {
         *reinterpret_cast<u32x4 *>(buf + 16 * tid) = r0;
     };
 
-    const int64_t G = a.n_main_blocks;
-    int64_t t = blockIdx.x;
+    // tile indices fit 32 bits (the launcher refuses more than 2^30 tiles = 4 TiB of text per launch);
+    // 64-bit loop state would not fit the SGPR budget and spill
+    const int G = a.n_main_blocks;
+    const int ntiles = (int)a.ntiles;
+    int t = (int)blockIdx.x;
     u32x4 ra0 = {0, 0, 0, 0}, rb0 = {0, 0, 0, 0};
 
     // LDS-DMA of one tile: lane L's 16 bytes land at (buffer + wave*1024) + 16*L.  Lanes outside the
@@ -784,8 +788,8 @@ void apm_filter_kernel(ApmFilterArgs a) {
     const uint32_t lds0 = __builtin_amdgcn_groupstaticsize();
     const uint32_t wave_off = __builtin_amdgcn_readfirstlane((uint32_t)tid >> 6) * 1024u;
     const uint32_t lane_off = 16u * (uint32_t)tid;
-    auto dma = [&](int64_t tt, int buf) __attribute__((always_inline)) {
-        const int64_t gt = a.tile0 + tt * a.tile_w - a.front; // tile start (uniform)
+    auto dma = [&](int tt, int buf) __attribute__((always_inline)) {
+        const int64_t gt = a.tile0 + (int64_t)tt * a.tile_w - a.front; // tile start (uniform)
         const uint32_t base = lds0 + (uint32_t)buf * (uint32_t)APM_FILTER_POS + wave_off;
         uint32_t keep;
         if (gt >= 0 && gt + APM_FILTER_POS <= a.avail_pad) { // whole tile inside the text: scalar base + lane offset
@@ -809,9 +813,9 @@ void apm_filter_kernel(ApmFilterArgs a) {
 
     if constexpr (DMA) {
         for (int b = 0; b < 3; ++b)
-            if (t + b * G < a.ntiles) dma(t + b * G, b);
+            if (t + b * G < ntiles) dma(t + b * G, b);
     } else {
-        if (t < a.ntiles) fetch(t, ra0);
+        if (t < ntiles) fetch(t, ra0);
     }
     // the launch image is ONE contiguous blob laid out like its LDS copy: a single round of
     // 16-byte loads, one wait (separate small copies would chain their HBM latencies)
@@ -820,10 +824,10 @@ void apm_filter_kernel(ApmFilterArgs a) {
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
     if (tid < 2) s_qn[tid] = 0u;
     if constexpr (!DMA) {
-        if (t < a.ntiles) {
+        if (t < ntiles) {
             stash(s_tile0, ra0);
-            if (t + G < a.ntiles) fetch(t + G, ra0);         // A: tile t+G   -> lands in buffer 1
-            if (t + 2 * G < a.ntiles) fetch(t + 2 * G, rb0); // B: tile t+2G -> lands in buffer 0
+            if (t + G < ntiles) fetch(t + G, ra0);         // A: tile t+G   -> lands in buffer 1
+            if (t + 2 * G < ntiles) fetch(t + 2 * G, rb0); // B: tile t+2G -> lands in buffer 0
         }
     }
     __syncthreads(); // (drains the prologue loads, DMA included)
@@ -890,6 +894,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
     };
     auto verify_item = [&](const uint8_t *s_tile, int64_t base, int kid, int pos, int dl_lo, int dl_hi) __attribute__((always_inline)) {
         if (!stage1_item(s_tile, kid, pos)) return;
+        if (a.ablate & 16) return; // measurement aid: skip the banded DP
         for (int dl = dl_lo; dl <= dl_hi; ++dl) dp_item(s_tile, base, kid, pos, dl);
     };
 
@@ -943,12 +948,15 @@ void apm_filter_kernel(ApmFilterArgs a) {
             const uint32_t clo = pk[0] | (pk[1] << 8) | (pk[2] << 16) | (pk[3] << 24);
             const uint32_t chi = pk[4] | (pk[5] << 8);
             constexpr int LB = 2 * KL - 3; // log2 of the bitmap's byte count
+            // the bitmap leads the image, and these kernels own no static LDS (tests check the build's
+            // resource digest): its LDS address is a compile-time constant -> no address add per probe
+            const apm_lds_u8 *bmp0 = (const apm_lds_u8 *)(uintptr_t)(NBUF * APM_FILTER_POS);
             uint32_t hits = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 16; ++i) { // and, ds_read_u8, 2 x v_bfe_u32, v_lshl_or_b32 per position
                 const uint32_t x = i ? __builtin_amdgcn_alignbit(chi, clo, 2u * (uint32_t)i) : clo;
-                const uint32_t byte = s_bmp[x & ((1u << LB) - 1u)];
-                hits |= ((byte >> ((x >> LB) & 7u)) & 1u) << i;
+                const uint32_t byte = bmp0[x & ((1u << LB) - 1u)];
+                hits |= __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(x, LB, 3), 1) << i;
             }
             while (hits) {
                 const int i = __builtin_ctz(hits);
@@ -961,8 +969,8 @@ void apm_filter_kernel(ApmFilterArgs a) {
 
     // cooperative verification of the candidates queued for tile t (held in s_tile); the queue must be
     // complete (a barrier since its filter)
-    auto verify_tile = [&](const uint8_t *s_tile, int64_t t, int qa, int qc) __attribute__((always_inline)) {
-        const int64_t base = a.tile0 + t * a.tile_w; // first window start of the tile
+    auto verify_tile = [&](const uint8_t *s_tile, int t, int qa, int qc) __attribute__((always_inline)) {
+        const int64_t base = a.tile0 + (int64_t)t * a.tile_w; // first window start of the tile
         const int p0 = tid * 16;
         constexpr int NF = 16 / STRIDE;
         const uint32_t *queue = s_queue + qa * a.qcap;
@@ -1060,12 +1068,12 @@ void apm_filter_kernel(ApmFilterArgs a) {
     };
 
     if constexpr (DMA) {
-        for (int it = 0; t < a.ntiles; ++it, t += G) {
+        for (int it = 0; t < ntiles; ++it, t += G) {
             // tile t (DMA issued two iterations ago) must have landed; the DMA of tile t+G stays in flight
-            if (t + G < a.ntiles) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t + G < ntiles) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // every wave is past tile t-G now: its buffer takes tile t+2G
-            if (it >= 1 && t + 2 * G < a.ntiles && !(a.ablate & 2)) dma(t + 2 * G, (it + 2) % 3);
+            if (it >= 1 && t + 2 * G < ntiles && !(a.ablate & 2)) dma(t + 2 * G, (it + 2) % 3);
             const uint8_t *s_tile = smem + (it % 3) * APM_FILTER_POS;
             filter_tile(s_tile, it & 1, it & 1);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
@@ -1075,20 +1083,20 @@ void apm_filter_kernel(ApmFilterArgs a) {
     } else {
         // one iteration: filter tile t, barrier, verify it, then land the registers `r` (tile t+G) in the
         // other buffer and refill them with tile t+3G
-        auto iteration = [&](int it, int64_t t, const uint8_t *s_tile, uint8_t *s_other, u32x4 &r0) __attribute__((always_inline)) {
+        auto iteration = [&](int it, int t, const uint8_t *s_tile, uint8_t *s_other, u32x4 &r0) __attribute__((always_inline)) {
             filter_tile(s_tile, it & 1, it & 1);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
             if (tid == 0) s_qn[(it + 1) & 1] = 0u; // next iteration's counter (nobody reads it before barrier B)
             verify_tile(s_tile, t, it & 1, it & 1);
-            if (t + G < a.ntiles) {
+            if (t + G < ntiles) {
                 stash(s_other, r0);
-                if (t + 3 * G < a.ntiles && !(a.ablate & 2)) fetch(t + 3 * G, r0);
+                if (t + 3 * G < ntiles && !(a.ablate & 2)) fetch(t + 3 * G, r0);
             }
             __syncthreads(); // B
         };
-        for (int it = 0; t < a.ntiles; it += 2, t += 2 * G) {
+        for (int it = 0; t < ntiles; it += 2, t += 2 * G) {
             iteration(it, t, s_tile0, s_tile1, ra0);
-            if (t + G < a.ntiles) iteration(it + 1, t + G, s_tile1, s_tile0, rb0);
+            if (t + G < ntiles) iteration(it + 1, t + G, s_tile1, s_tile0, rb0);
         }
     }
     __syncthreads();
@@ -1170,7 +1178,7 @@ __device__ __forceinline__ bool apm_ext_bwd_g(const uint8_t *text, int64_t limit
 }
 
 template <int BAND, int KL, int STRIDE>
-__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 7 : ((BAND >= 2 || STRIDE == 1) ? 4 : 5))
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 7 : ((BAND >= 1 && STRIDE == 1) ? 3 : ((BAND >= 2 || STRIDE == 1) ? 4 : 5)))
 void apm_stream_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1179,13 +1187,12 @@ void apm_stream_kernel(ApmFilterArgs a) {
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
-    constexpr int NF = 16 / STRIDE;
     constexpr int NSH = 2 * BAND + 1;
     constexpr bool PAIRS = (STRIDE == 1) && (BAND >= 1);
-    constexpr int GRP = STRIDE == 1 ? 4 : 4 * NF; // probes between two flush checks (sampled classes: 4 chunks)
+    constexpr int GRP = 4;                        // probes between two flush checks
     constexpr int QW = 64 * GRP + 64;             // wave queue entries: flushed as soon as it holds >= 64
     uint8_t *s_img = smem;
-    uint8_t *s_pat = s_img;
+    uint8_t *s_pat = s_img + a.o_pat;
     const uint4 *s_tab = reinterpret_cast<const uint4 *>(s_img + a.o_tab);
     const uint4 *s_kid = reinterpret_cast<const uint4 *>(s_img + a.o_kid);
     const uint32_t *s_ovf = reinterpret_cast<const uint32_t *>(s_img + a.o_ovf);
@@ -1212,7 +1219,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
         const uint32_t nrec = lim <= 0 ? 0u : (lim > 1040 ? 1040u : (uint32_t)lim);
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
-        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0); // (nt / sc0 / sc1 cache-policy bits measured: no gain, nt loses 4 %)
         if constexpr (STRIDE == 1) { // the 8 bytes behind the lane's 16 (next lane's / next chunk's head)
             typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
             const u32x2v x = __builtin_amdgcn_raw_buffer_load_b64(rs, 16 * lane + 16, 0, 0);
@@ -1293,8 +1300,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
             const uint2 ent = s_queue[PAIRS ? wi : wi / NSH];
             const int dl_lo = PAIRS ? -BAND : (int)(wi % NSH) - BAND;
             const int dl_hi = PAIRS ? BAND : dl_lo;
-            const uint32_t tag = ent.y & 0xffffu;
-            const int64_t pos = (int64_t)ent.x | ((int64_t)(ent.y >> 16) << 32);
+            const int64_t pos = (int64_t)ent.x | ((int64_t)ent.y << 32);
             if (pos + KL > a.avail) continue;
             uint32_t fw[(KL + 3) / 4];
             apm_gdwords<(KL + 3) / 4>(text, limit, pos, fw);
@@ -1302,7 +1308,9 @@ void apm_stream_kernel(ApmFilterArgs a) {
             if constexpr (KL == 16) fi = apm_fp16(apm_fp8(fw[0], fw[1]), apm_fp8(fw[2], fw[3]));
             else if constexpr (KL > 4) fi = apm_fp8(fw[0], fw[1] & apm_hi_mask<KL>());
             else fi = fw[0];
-            const uint32_t slot = apm_table_hash<KL>(fi) >> hshift;
+            const uint32_t hh = apm_table_hash<KL>(fi);
+            const uint32_t slot = hh >> hshift;
+            const uint32_t tag = hh & 0xffffu; // (the bitmap filter queues bare positions)
             uint32_t first = 0xffffffffu; // this lane's matching way, verified with the whole wave
             int n_match = 0;
             {
@@ -1362,6 +1370,60 @@ void apm_stream_kernel(ApmFilterArgs a) {
     };
 
     uint32_t qcount = 0; // wave-uniform
+    auto drain = [&]() __attribute__((always_inline)) {
+        if (qcount >= 64u) {
+            flush(qcount);
+            qcount = 0;
+        }
+    };
+    // First-level filter of the per-position classes: a presence bitmap over the 2-bit byte codes
+    // (b >> code_shift) & 3 of the key bytes (built by the host next to the hash table).  The lane packs
+    // the codes of its 24 bytes into a bit string once; the code word of position i is a 2i-bit funnel
+    // shift of it and its bit sits in byte x & (NB-1) of the bitmap, bit x >> log2(NB).  Returns the
+    // lane's 16-bit hit mask (bit i = position i of its 16 bytes).
+    auto pack4 = [&](uint32_t wv4) __attribute__((always_inline)) { // 4 bytes -> 8 code bits
+        const uint32_t cd = (wv4 >> a.code_shift) & 0x03030303u;
+        const uint32_t u = cd | (cd >> 6);
+        return (u | (u >> 12)) & 0xffu;
+    };
+    constexpr int LB = 2 * (KL > 8 ? 8 : KL) - 3; // log2 of the bitmap's byte count
+    // the bitmap leads the image = the start of dynamic LDS, and this kernel owns no static LDS (tests
+    // check the build's resource digest): LDS address 0, a compile-time constant -> no address add per probe
+    const apm_lds_u8 *bmp0 = (const apm_lds_u8 *)(uintptr_t)0;
+    auto bmp_bit = [&](uint32_t x) __attribute__((always_inline)) { // and, ds_read_u8, 2 x v_bfe_u32
+        const uint32_t byte = bmp0[x & ((1u << LB) - 1u)];
+        return __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(x, LB, 3), 1);
+    };
+    auto hit_bits = [&](const u32x4 &v, const uint2 &e, int64_t cc) __attribute__((always_inline)) {
+        if (a.ablate & 32) return (v.x ^ e.x) == 0x12345u ? 1u : 0u; // measurement aid: streaming skeleton only
+        uint32_t hits = 0;
+        const uint32_t clo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+        const uint32_t chi = pack4(e.x) | (pack4(e.y) << 8);
+#pragma unroll
+        for (int i = 15; i >= 0; --i) // descending: hits = hits << 1 | bit (one v_lshl_or_b32 each)
+            hits = (hits << 1) | bmp_bit(i ? __builtin_amdgcn_alignbit(chi, clo, 2u * (uint32_t)i) : clo);
+        return (cc < nch && !(a.ablate & 1)) ? hits : 0u;
+    };
+    // the hit positions of one chunk go to the wave queue, one bit per lane and round (<= 16 rounds of
+    // <= 64 positions); the queue is verified as soon as it holds a wave's worth
+    auto push_hits = [&](uint32_t hits, int64_t cc) __attribute__((always_inline)) {
+        const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
+        while (__builtin_amdgcn_ballot_w64(hits != 0)) {
+            const bool has = hits != 0;
+            const int i = has ? __builtin_ctz(hits) : 0;
+            hits &= hits - 1u; // (0 stays 0)
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const int64_t pp = pos + i;
+            if (has) s_queue[idx] = make_uint2((uint32_t)pp, (uint32_t)(pp >> 32));
+            qcount += (uint32_t)__builtin_popcountll(mask);
+            drain();
+        }
+    };
+
+    // sampled classes: one (stride 16) or two (stride 8) fingerprints per lane and chunk probe the hash
+    // table directly (8 x 16-bit tags per bucket, v_pk_min_u16 match); hits are queued on the spot.
+    // (A bitmap first level was measured here too: no gain at one or two probes per lane.)
     auto probe = [&](uint32_t fi, int64_t pos, bool valid) __attribute__((always_inline)) {
         const uint32_t h = apm_table_hash<KL>(fi);
         const uint32_t slot = h >> hshift;
@@ -1377,62 +1439,38 @@ void apm_stream_kernel(ApmFilterArgs a) {
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
         if (mask) { // rare with long keys
             const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (hit) s_queue[idx] = make_uint2((uint32_t)pos, ((uint32_t)(pos >> 32) << 16) | tag);
+            if (hit) s_queue[idx] = make_uint2((uint32_t)pos, (uint32_t)(pos >> 32));
             qcount += (uint32_t)__builtin_popcountll(mask);
         }
     };
-    auto drain = [&]() __attribute__((always_inline)) {
-        if (qcount >= 64u) {
-            flush(qcount);
-            qcount = 0;
-        }
-    };
-    auto process = [&](const u32x4 &v, const uint2 &e, int64_t cc) __attribute__((always_inline)) {
+    auto process = [&](const u32x4 &v, int64_t cc) __attribute__((always_inline)) {
         const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
         const bool valid = cc < nch && !(a.ablate & 1);
-        if constexpr (STRIDE == 16) { // (sampled classes: the caller drains once per four chunks)
+        if constexpr (STRIDE == 16) {
             probe(apm_fp16(apm_fp8(v.x, v.y), apm_fp8(v.z, v.w)), pos, valid);
         } else if constexpr (STRIDE == 8) {
             probe(apm_fp8(v.x, v.y), pos, valid);
             probe(apm_fp8(v.z, v.w), pos + 8, valid);
-        } else { // every position, KL = 8, 6 or 4 key bytes: four groups of four probes, ONE drain site
-            const uint32_t w[6] = {v.x, v.y, v.z, v.w, e.x, e.y};
-#pragma unroll 1
-            for (int g = 0; g < 4; ++g) {
-                uint32_t wa, wb, wc; // the three dwords covering positions 4g .. 4g+3 (+ 8 key bytes)
-                switch (g) {
-                case 0: wa = w[0]; wb = w[1]; wc = w[2]; break;
-                case 1: wa = w[1]; wb = w[2]; wc = w[3]; break;
-                case 2: wa = w[2]; wb = w[3]; wc = w[4]; break;
-                default: wa = w[3]; wb = w[4]; wc = w[5]; break;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t lo = i ? __builtin_amdgcn_alignbyte(wb, wa, (uint32_t)i) : wa;
-                    uint32_t fi = lo;
-                    if constexpr (KL > 4) {
-                        const uint32_t hi = i ? __builtin_amdgcn_alignbyte(wc, wb, (uint32_t)i) : wb;
-                        fi = apm_fp8(lo, hi & apm_hi_mask<KL>());
-                    }
-                    probe(fi, pos + 4 * g + i, valid);
-                }
-                drain();
-            }
         }
     };
 
+    // four chunks in flight per lane.  Per-position classes: the four bitmap passes only produce hit
+    // masks and ONE runtime loop queues them, so the kernel holds a single copy of the verification code.
     int64_t c = (int64_t)blockIdx.x * (APM_BLOCK / 64) + wv;
-    if constexpr (STRIDE == 1) {
-        // probe-bound classes: one chunk in flight per lane is enough (several waves per SIMD overlap),
-        // and ONE process site keeps a single copy of the verification code
-        u32x4 r;
-        uint2 e = make_uint2(0, 0);
-        load_chunk(c, r, e);
-        for (; c < nch; c += W) {
-            const u32x4 v = r;
-            const uint2 ev = e;
-            load_chunk(c + W, r, e);
-            process(v, ev, c);
+    if constexpr (STRIDE > 1) {
+        u32x4 r0, r1, r2, r3;
+        uint2 e0 = make_uint2(0, 0), e1 = e0, e2 = e0, e3 = e0;
+        load_chunk(c, r0, e0);
+        load_chunk(c + W, r1, e1);
+        load_chunk(c + 2 * W, r2, e2);
+        load_chunk(c + 3 * W, r3, e3);
+        for (; c < nch; c += 4 * W) {
+            { const u32x4 v = r0; load_chunk(c + 4 * W, r0, e0); process(v, c); }
+            { const u32x4 v = r1; load_chunk(c + 5 * W, r1, e1); process(v, c + W); }
+            if constexpr (STRIDE == 8) drain(); // four positions queued: keeps the wave queue (LDS) small
+            { const u32x4 v = r2; load_chunk(c + 6 * W, r2, e2); process(v, c + 2 * W); }
+            { const u32x4 v = r3; load_chunk(c + 7 * W, r3, e3); process(v, c + 3 * W); }
+            drain(); // few verification sites: keeps the loop small and its uniform state in SGPRs
         }
     } else {
         u32x4 r0, r1, r2, r3;
@@ -1442,11 +1480,15 @@ void apm_stream_kernel(ApmFilterArgs a) {
         load_chunk(c + 2 * W, r2, e2);
         load_chunk(c + 3 * W, r3, e3);
         for (; c < nch; c += 4 * W) {
-            { const u32x4 v = r0; const uint2 e = e0; load_chunk(c + 4 * W, r0, e0); process(v, e, c); }
-            { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 5 * W, r1, e1); process(v, e, c + W); }
-            { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 6 * W, r2, e2); process(v, e, c + 2 * W); }
-            { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 7 * W, r3, e3); process(v, e, c + 3 * W); }
-            drain(); // ONE verification site: keeps the loop small and its uniform state in SGPRs
+            uint32_t h0, h1, h2, h3;
+            { const u32x4 v = r0; const uint2 e = e0; load_chunk(c + 4 * W, r0, e0); h0 = hit_bits(v, e, c); }
+            { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 5 * W, r1, e1); h1 = hit_bits(v, e, c + W); }
+            { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 6 * W, r2, e2); h2 = hit_bits(v, e, c + 2 * W); }
+            { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 7 * W, r3, e3); h3 = hit_bits(v, e, c + 3 * W); }
+            if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j * W);
+            }
         }
     }
     flush(qcount);
@@ -1459,8 +1501,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
 }
 
 static size_t apm_stream_lds_bytes(const ApmFilterArgs &a) {
-    const int nf = 16 / a.stride;
-    const size_t qw = (size_t)(64 * (a.stride == 1 ? 4 : 4 * nf) + 64);
+    const size_t qw = (size_t)(64 * 4 + 64); // = QW of the kernel
     size_t b = (size_t)a.image_len + 4 * qw * 8 + (size_t)((a.n_pats + 3) & ~3) * 4 + 16;
     return b < 4608 ? 4608 : b; // the tail workgroups need 256 uint4 + 128 bytes
 }
@@ -1469,9 +1510,15 @@ template <int BAND>
 static const void *apm_stream_fn_kl(int kl, int stride) {
     if (kl == 16 && stride == 16) return (const void *)apm_stream_kernel<BAND, 16, 16>;
     if (kl == 8 && stride == 8) return (const void *)apm_stream_kernel<BAND, 8, 8>;
-    // The per-position classes (stride 1) are NOT instantiated: measured on MI355X the wave-autonomous
-    // form loses to the LDS-tile kernel there (verification against global text, whole-wave DP after a
-    // single lane's pre-check: cfg5 20 ms vs 4.9 ms per GiB), so they stay on apm_filter_kernel.
+    // Per-position classes: the host picks this form only for launches whose keys are expected to hit
+    // rarely (few keys per 4^key_len codes).  With frequent candidates the LDS-tile kernel wins clearly
+    // (verification against global text: cfg5 20 ms vs 3.6 ms per GiB on MI355X).
+    // Wider bands (k >= 4) would spill there and stay on the tile kernel.
+    if constexpr (BAND <= 1) {
+        if (kl == 8 && stride == 1) return (const void *)apm_stream_kernel<BAND, 8, 1>;
+        if (kl == 6 && stride == 1) return (const void *)apm_stream_kernel<BAND, 6, 1>;
+        if (kl == 4 && stride == 1) return (const void *)apm_stream_kernel<BAND, 4, 1>;
+    }
     return nullptr;
 }
 static const void *apm_stream_fn(int band, int kl, int stride) {
@@ -1551,6 +1598,7 @@ int apm_filter_blocks_per_cu(int band, int kl, int stride, int dma, size_t lds) 
 
 hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t s) {
     if (a.ntiles <= 0 || a.n_pats <= 0) return hipSuccess;
+    if (a.ntiles > ((int64_t)1 << 30)) return hipErrorInvalidValue; // 32-bit tile indices in the kernel
     const void *fn = apm_filter_fn(a.band, a.key_len, a.stride, a.use_dma);
     if (!fn) return hipErrorInvalidValue;
     const size_t lds = apm_filter_lds_bytes(a);

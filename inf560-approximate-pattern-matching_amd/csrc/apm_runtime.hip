@@ -66,7 +66,8 @@ struct TiledLaunch {       // host description of one tiled scan launch
     std::vector<uint32_t> pinfo;      // BANDED: per pattern {byte_off | m<<16, aux_off}
     std::vector<uint8_t> image;       // BANDED: LDS image (bytes | table | kids | ovf | kinfo | pinfo)
     int o_tab = 0, o_kid = 0, o_ovf = 0, o_kinfo = 0, o_pinfo = 0, o_next = 0, o_poff = 0;
-    int o_bmp = 0, code_shift = 1; // per-position classes: key bitmap over 2-bit byte codes
+    int o_bmp = 0, code_shift = 1; // per-position classes: key bitmap over 2-bit byte codes (leads the image)
+    int o_pat = 0;                 // pattern bytes inside the image
     int key_len = 0, stride = 0;      // BANDED: (16,16), (8,8) or (8,1)
     int nb = 0, lg_nb = 0, qcap = 0;
     int a_max = 0;                    // BANDED: largest key offset
@@ -483,16 +484,6 @@ int build_plan(apm_ctx *ctx) {
                 if (bytes) memcpy(L.image.data() + at, src, bytes);
                 return (int)at;
             };
-            append(L.bytes.data(), L.bytes.size());
-            L.o_tab = append(L.table.data(), L.table.size() * 2);
-            L.o_kid = append(L.table_kid.data(), L.table_kid.size() * 2);
-            L.o_ovf = append(L.ovf.data(), L.ovf.size() * 4);
-            L.o_kinfo = append(L.kinfo.data(), L.kinfo.size() * 4);
-            L.o_pinfo = append(L.pinfo.data(), L.pinfo.size() * 4);
-            std::vector<uint16_t> nxt;
-            for (const ApmKey &kk : L.keys) nxt.push_back(kk.next);
-            L.o_next = append(nxt.data(), nxt.size() * 2);
-            L.o_poff = append(L.piece_off.data(), L.piece_off.size() * 2);
             if (stride == 1) {
                 // First-level filter of the per-position classes: a presence bitmap indexed by the 2-bit
                 // codes (b >> s) & 3 of the key bytes.  s is picked to spread this launch's pattern bytes
@@ -506,17 +497,30 @@ int build_plan(apm_ctx *ctx) {
                                        (hist[0] > 0) + (hist[1] > 0) + (hist[2] > 0) + (hist[3] > 0) + (sft == 1);
                     if (score > best) { best = score; L.code_shift = sft; }
                 }
-                const uint32_t nbytes = 1u << (2 * klen - 3);
+                const int kc = std::min(klen, 8); // key bytes the bitmap covers
+                const uint32_t nbytes = 1u << (2 * kc - 3);
                 std::vector<uint8_t> bmp(nbytes, 0);
                 for (const ApmKey &kk : L.keys) {
                     const ApmPatDesc &dd = L.descs[kk.pat];
                     uint32_t x = 0;
-                    for (int z = 0; z < klen; ++z)
-                        x |= (uint32_t)((L.bytes[dd.byte_off + kk.off + z] >> L.code_shift) & 3) << (2 * z);
-                    bmp[x & (nbytes - 1)] |= (uint8_t)(1u << (x >> (2 * klen - 3)));
+                    for (int z = 0; z < kc; ++z) { // (sampled keys may run past the pattern: zero padded like the key itself)
+                        const unsigned char b = kk.off + z < (int)dd.m ? L.bytes[dd.byte_off + kk.off + z] : 0;
+                        x |= (uint32_t)((b >> L.code_shift) & 3) << (2 * z);
+                    }
+                    bmp[x & (nbytes - 1)] |= (uint8_t)(1u << (x >> (2 * kc - 3)));
                 }
-                L.o_bmp = append(bmp.data(), bmp.size());
+                L.o_bmp = append(bmp.data(), bmp.size()); // = 0: a compile-time LDS address for the probes
             }
+            L.o_pat = append(L.bytes.data(), L.bytes.size());
+            L.o_tab = append(L.table.data(), L.table.size() * 2);
+            L.o_kid = append(L.table_kid.data(), L.table_kid.size() * 2);
+            L.o_ovf = append(L.ovf.data(), L.ovf.size() * 4);
+            L.o_kinfo = append(L.kinfo.data(), L.kinfo.size() * 4);
+            L.o_pinfo = append(L.pinfo.data(), L.pinfo.size() * 4);
+            std::vector<uint16_t> nxt;
+            for (const ApmKey &kk : L.keys) nxt.push_back(kk.next);
+            L.o_next = append(nxt.data(), nxt.size() * 2);
+            L.o_poff = append(L.piece_off.data(), L.piece_off.size() * 2);
             ctx->tiled.push_back(std::move(L));
         }
     }
@@ -660,6 +664,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.o_next = L.o_next;
             f.o_poff = L.o_poff;
             f.o_bmp = L.o_bmp;
+            f.o_pat = L.o_pat;
             f.code_shift = L.code_shift;
             f.nk = (int)L.keys.size();
             f.nb = L.nb;
@@ -684,7 +689,11 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             }
             // APM_FILTER_STREAM=0 forces the tile kernel (A/B aid); default: stream kernel for the sampled classes
             static const int stream_env = getenv("APM_FILTER_STREAM") ? atoi(getenv("APM_FILTER_STREAM")) : 1;
-            if (stream_env && L.stride > 1 && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
+            // per-position classes stream only when candidates are expected to be rare (verification then
+            // reads global text, dense 64-candidate batches); APM_FILTER_STREAM=2 forces, 3 forbids (A/B aid)
+            const double hit_rate = (double)L.keys.size() / (double)(1ull << (2 * std::min(L.key_len, 8)));
+            const bool stream_ok = L.stride > 1 || (f.band <= 1 && (stream_env == 2 || (stream_env != 3 && hit_rate < 1.0 / 200.0)));
+            if (stream_env && stream_ok && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
                 // wave-autonomous streaming kernel over 1 KiB chunks
                 const int64_t p_lo = std::max<int64_t>(0, jb - f.band) & ~(int64_t)15;
                 const int64_t p_hi = std::min<int64_t>(avail, je_l + L.m_max + f.band);

@@ -3,6 +3,7 @@
   (2) the oracle restatement on seeded inputs,
   (3) size-independent properties at BASELINE.json's full sizes.
 Bit-exact integer counts everywhere (no tolerance)."""
+import json
 import os
 import random
 import subprocess
@@ -553,3 +554,52 @@ def test_cli_positions_flag():
     for l, p, cnt in zip(pos_lines, c["patterns"], c["counts"]):
         got = [int(x) for x in l.split(">:", 1)[1].split()]
         assert len(got) == cnt and got == _oracle_positions(text, p, c["k"])
+
+
+# ---------------------------------------------------------------- every kernel form of the BANDED path
+_FORM_WORKER = r"""
+import json, random, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import helpers as H
+apm = H.pkg()
+rng = random.Random(20241)
+text = bytearray(rng.choice(b"ACGT") for _ in range(300000))
+out = {}
+for k in (0, 1, 3, 4):
+    pats = []
+    for m in (16, 20, 27, 30, 40, 59, 64, 100, 128):
+        o = rng.randrange(0, len(text) - m)
+        p = bytearray(text[o:o + m])
+        for _ in range(rng.randrange(0, k + 2)):          # substitutions
+            p[rng.randrange(m)] = rng.choice(b"ACGT")
+        if k >= 2 and rng.random() < 0.5:                  # one deletion + one insertion (keeps the length)
+            i, j = sorted(rng.sample(range(1, m - 1), 2))
+            del p[i]; p.insert(j, rng.choice(b"ACGT"))
+        pats.append(bytes(p))
+    with apm.ApmContext(device=0) as ctx:
+        ctx.set_patterns(pats, k)
+        out[str(k)] = dict(patterns=[p.decode() for p in pats], counts=ctx.count_buffer(bytes(text)),
+                           kernels=[ctx.pattern_kernel(i) for i in range(len(pats))])
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("env", [{}, {"APM_FILTER_STREAM": "0"}, {"APM_FILTER_STREAM": "2"}, {"APM_FILTER_STREAM": "3"},
+                                 {"APM_FILTER_DMA": "0"}, {"APM_FILTER_STREAM": "2", "APM_FILTER_DMA": "0"}],
+                         ids=lambda e: ",".join("%s=%s" % (k[11:], v) for k, v in e.items()) or "default")
+def test_every_filter_kernel_form_agrees_with_oracle(env):
+    """The BANDED path picks between the LDS-tile kernel (LDS-DMA or register-staged) and the wave-autonomous
+    stream kernel per launch; the APM_FILTER_* switches force each form (they are read once per process,
+    hence the subprocess).  All forms must give the oracle's counts."""
+    r = subprocess.run([os.sys.executable, "-c", _FORM_WORKER, H.ROOT, os.path.join(H.ROOT, "tests")],
+                       capture_output=True, env=dict(os.environ, **env), timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    rng = random.Random(20241)
+    text = bytes(bytearray(rng.choice(b"ACGT") for _ in range(300000)))
+    for k, res in got.items():
+        pats = [p.encode() for p in res["patterns"]]
+        for p, kern in zip(pats, res["kernels"]):
+            assert kern == (4 if len(p) // (int(k) + 1) >= 4 else 3), "BANDED wherever the pieces are long enough"
+        assert res["counts"] == H.oracle_counts(text, pats, int(k), banded=True), (k, env)
+        assert sum(res["counts"]) >= 5

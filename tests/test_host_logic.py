@@ -101,4 +101,7 @@ def test_no_kernel_spills_to_scratch():
         elif line.startswith("ScratchSize"):
             seen += 1
             assert int(line.rsplit(":", 1)[1]) == 0, "%s spills to scratch" % name
+        elif line.startswith("LDS Size") and ("apm_filter_kernel" in name or "apm_stream_kernel" in name):
+            # their key bitmap is addressed as a compile-time LDS constant: dynamic LDS must start at 0
+            assert int(line.rsplit(":", 1)[1]) == 0, "%s owns static LDS" % name
     assert seen >= 40
