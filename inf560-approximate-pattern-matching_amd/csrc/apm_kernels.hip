@@ -756,7 +756,9 @@ void apm_filter_kernel(ApmFilterArgs a) {
     const uint16_t *s_poff = reinterpret_cast<const uint16_t *>(s_img + a.o_poff); // piece offsets a_q
     uint32_t *s_queue = reinterpret_cast<uint32_t *>(s_img + a.image_len); // 2 x qcap
     uint32_t *s_cnt = s_queue + 2 * a.qcap;
-    uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [2] queue counters
+    uint32_t *s_qn = s_cnt + ((a.n_pats + 3) & ~3); // [2] queue counters, [4..7] per-wave survivor counters
+    constexpr int SCAP = 128;                       // per-wave list of pre-check survivors (kid | pos << 16)
+    uint32_t *s_surv = s_qn + 8;
 
     // Branch-free tile fetch: ONE raw buffer load of 16 bytes per lane per tile (tile = 4096 bytes),
     // the descriptor's num_records does the bounds check (out-of-range lanes return 0 and move no
@@ -978,8 +980,23 @@ void apm_filter_kernel(ApmFilterArgs a) {
         constexpr int NSH = 2 * BAND + 1;
         // all keys whose tag matches at this sampled position (bucket ways, overflow list, chains);
         // one runtime loop = ONE inlined copy of the verification code
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         auto for_each_key = [&](uint32_t tag, int pos, int dl_lo, int dl_hi) __attribute__((always_inline)) {
-            auto handle = [&](int kid) __attribute__((always_inline)) { verify_item(s_tile, base, kid, pos, dl_lo, dl_hi); };
+            auto handle = [&](int kid) __attribute__((always_inline)) {
+                if constexpr (PAIRS) {
+                    // pre-check here, banded DP later: the survivors (few per wave) go to a wave-private list so
+                    // that the DP runs on dense lanes, one (survivor, shift) each, instead of inside this
+                    // divergent walk with the three shifts in sequence
+                    if (!stage1_item(s_tile, kid, pos)) return;
+                    if (a.ablate & 16) return; // measurement aid: skip the banded DP
+                    const uint32_t idx = atomicAdd(&s_qn[4 + wv], 1u);
+                    if (idx < (uint32_t)SCAP) s_surv[wv * SCAP + idx] = (uint32_t)kid | ((uint32_t)pos << 16);
+                    else
+                        for (int dl = dl_lo; dl <= dl_hi; ++dl) dp_item(s_tile, base, kid, pos, dl); // list full (rare)
+                } else {
+                    verify_item(s_tile, base, kid, pos, dl_lo, dl_hi);
+                }
+            };
             uint32_t fw[(KL + 3) / 4];
             apm_lds_dwords<(KL + 3) / 4>(s_tile, pos, fw);
             uint32_t fi;
@@ -1049,10 +1066,18 @@ void apm_filter_kernel(ApmFilterArgs a) {
         };
         if (a.ablate & 8) { // measurement aid: skip verification
         } else if (qn <= (uint32_t)a.qcap) {
-            if constexpr (PAIRS) { // work item = queue entry: the cheap pair pre-check runs once, shifts inside
+            if constexpr (PAIRS) { // work item = queue entry: the cheap pair pre-check runs once per entry ...
+                if ((tid & 63) == 0) s_qn[4 + wv] = 0u; // (wave-private: LDS operations of one wave stay in order)
                 for (uint32_t wi = tid; wi < qn; wi += APM_BLOCK) {
                     const uint32_t ent = queue[wi];
                     for_each_key(ent >> 16, (int)(ent & 0xffffu), -BAND, BAND);
+                }
+                // ... then work item = (survivor, shift) of this wave's list
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t ns = min(s_qn[4 + wv], (uint32_t)SCAP);
+                for (uint32_t wi = (uint32_t)(tid & 63); wi < ns * NSH; wi += 64) {
+                    const uint32_t e = s_surv[wv * SCAP + wi / NSH];
+                    dp_item(s_tile, base, (int)(e & 0xffffu), (int)(e >> 16), (int)(wi % NSH) - BAND);
                 }
             } else { // work item = (queue entry, shift): keeps all lanes busy
                 for (uint32_t wi = tid; wi < qn * NSH; wi += APM_BLOCK) {
@@ -1558,7 +1583,7 @@ hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t
 
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a) { // always >= 4352 B, which the tail workgroups need
     return (size_t)(a.use_dma ? 3 : 2) * (size_t)a.tile_len + (size_t)a.image_len + 2 * (size_t)a.qcap * 4 +
-           (size_t)((a.n_pats + 3) & ~3) * 4 + 16 + 16;
+           (size_t)((a.n_pats + 3) & ~3) * 4 + 32 + 4 * 128 * 4 + 16; // counters [8] + 4 survivor lists (SCAP = 128)
 }
 
 template <int BAND, int DMA>
