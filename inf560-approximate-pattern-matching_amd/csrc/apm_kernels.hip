@@ -1212,6 +1212,12 @@ void apm_stream_kernel(ApmFilterArgs a) {
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
+    // candidate-list modes (see ApmFilterArgs): a uniform early exit before anything is staged
+    unsigned long long n_cand = 0;
+    if (a.cand_mode) {
+        n_cand = *a.cand_n;
+        if ((a.cand_mode == 1) == (n_cand > a.cand_cap)) return; // verify-only of an overflowed list / fallback not needed
+    }
     constexpr int NSH = 2 * BAND + 1;
     constexpr bool PAIRS = (STRIDE == 1) && (BAND >= 1);
     constexpr int GRP = 4;                        // probes between two flush checks
@@ -1234,7 +1240,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
 
     const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
     const int64_t W = (int64_t)a.n_main_blocks * (APM_BLOCK / 64);
-    const int64_t nch = a.ntiles; // 1 KiB chunks from relative position a.tile0 (multiple of 16)
+    const int64_t nch = a.cand_mode == 1 ? 0 : a.ntiles; // 1 KiB chunks from relative position a.tile0 (multiple of 16)
     const uint8_t *text = a.text;
     const int64_t limit = a.avail_pad;
 
@@ -1516,13 +1522,136 @@ void apm_stream_kernel(ApmFilterArgs a) {
             }
         }
     }
-    flush(qcount);
+    // the last partial queue -- or, verify-only mode, the sieve's candidate list in batches of 64 per wave
+    // (same single verification site)
+    for (unsigned long long ci = (unsigned long long)((int64_t)blockIdx.x * (APM_BLOCK / 64) + wv) * 64u;;
+         ci += (unsigned long long)W * 64u) {
+        if (a.cand_mode == 1) {
+            if (ci >= n_cand) break;
+            const unsigned long long left = n_cand - ci;
+            qcount = left < 64u ? (uint32_t)left : 64u;
+            if ((uint32_t)lane < qcount) {
+                const unsigned long long pp = a.cand[ci + (unsigned long long)lane];
+                s_queue[lane] = make_uint2((uint32_t)pp, (uint32_t)(pp >> 32));
+            }
+        }
+        flush(qcount);
+        if (a.cand_mode != 1) break;
+    }
 
     __syncthreads();
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
         const uint32_t cnt = s_cnt[i];
         if (cnt) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)cnt);
     }
+}
+
+// ---------------------------------------------------------------------------
+// SIEVE: one wave-autonomous pass over the text for ALL sparse per-position classes of a pattern set.
+// Same chunking and loads as apm_stream_kernel (16 bytes per lane + the 8 that follow, four chunks in
+// flight), same 2-bit-code bitmap test per position -- against one 8 KiB bitmap over 8-byte code words
+// into which the host entered every participating key (a 6-byte key with its 16 extensions).  No
+// verification code lives here (~45 VGPRs, full occupancy): hit positions are appended to a global list,
+// one aggregated atomic per wave and round, and the per-class verify-only launches of apm_stream_kernel
+// take it from there.  An overflowing list (counter > capacity) turns those launches into no-ops and
+// their fallback twins into full scans, so the result never depends on the list fitting.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(APM_BLOCK, 5) void apm_sieve_kernel(ApmSieveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 512; i += APM_BLOCK) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
+    __syncthreads();
+    const apm_lds_u8 *bmp0 = (const apm_lds_u8 *)(uintptr_t)0; // the bitmap leads this kernel's LDS (no static LDS)
+    const int64_t W = (int64_t)gridDim.x * (APM_BLOCK / 64);
+    const int64_t nch = a.nchunks;
+
+    auto load_chunk = [&](int64_t cc, u32x4 &r, uint2 &e) __attribute__((always_inline)) {
+        const int64_t g = a.tile0 + cc * 1024;
+        const int64_t lim = cc < nch ? a.avail_pad - g : 0;
+        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1040 ? 1040u : (uint32_t)lim);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+        typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+        const u32x2v x = __builtin_amdgcn_raw_buffer_load_b64(rs, 16 * lane + 16, 0, 0);
+        e = make_uint2(x.x, x.y);
+    };
+    auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { // 4 bytes -> 8 code bits
+        const uint32_t cd = (w4 >> a.code_shift) & 0x03030303u;
+        const uint32_t u = cd | (cd >> 6);
+        return (u | (u >> 12)) & 0xffu;
+    };
+    auto hit_bits = [&](const u32x4 &v, const uint2 &e, int64_t cc) __attribute__((always_inline)) {
+        const uint32_t clo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+        const uint32_t chi = pack4(e.x) | (pack4(e.y) << 8);
+        uint32_t hits = 0;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            const uint32_t x = i ? __builtin_amdgcn_alignbit(chi, clo, 2u * (uint32_t)i) : clo;
+            const uint32_t byte = bmp0[x & 8191u];
+            hits = (hits << 1) | __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(x, 13, 3), 1);
+        }
+        return (cc < nch && !(a.ablate & 1)) ? hits : 0u;
+    };
+    // hit positions are staged in a wave-private LDS queue (ballot + mbcnt, no atomics) and leave for the
+    // global list 192+ at a time: one global atomic per batch, not per hit
+    constexpr int SQ = 256; // queue entries per wave: spilled to the list once it holds >= SQ - 64
+    unsigned long long *s_q = reinterpret_cast<unsigned long long *>(smem + 8192) + wv * SQ;
+    uint32_t qcount = 0; // wave-uniform
+    auto spill = [&]() __attribute__((always_inline)) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.cand_n, (unsigned long long)qcount);
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
+        for (uint32_t i = (uint32_t)lane; i < qcount; i += 64)
+            if (b + i < a.cand_cap) a.cand[b + i] = s_q[i];
+        qcount = 0;
+    };
+    auto push_hits = [&](uint32_t hits, int64_t cc) __attribute__((always_inline)) {
+        const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
+        while (__builtin_amdgcn_ballot_w64(hits != 0)) { // <= 16 rounds of <= 64 positions
+            const bool has = hits != 0;
+            const int i = has ? __builtin_ctz(hits) : 0;
+            hits &= hits - 1u; // (0 stays 0)
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (has) s_q[idx] = (unsigned long long)(pos + i);
+            qcount += (uint32_t)__builtin_popcountll(mask);
+            if (qcount >= (uint32_t)(SQ - 64)) spill();
+        }
+    };
+
+    int64_t c = (int64_t)blockIdx.x * (APM_BLOCK / 64) + wv;
+    u32x4 r0, r1, r2, r3;
+    uint2 e0 = make_uint2(0, 0), e1 = e0, e2 = e0, e3 = e0;
+    load_chunk(c, r0, e0);
+    load_chunk(c + W, r1, e1);
+    load_chunk(c + 2 * W, r2, e2);
+    load_chunk(c + 3 * W, r3, e3);
+    for (; c < nch; c += 4 * W) {
+        uint32_t h0, h1, h2, h3;
+        { const u32x4 v = r0; const uint2 e = e0; load_chunk(c + 4 * W, r0, e0); h0 = hit_bits(v, e, c); }
+        { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 5 * W, r1, e1); h1 = hit_bits(v, e, c + W); }
+        { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 6 * W, r2, e2); h2 = hit_bits(v, e, c + 2 * W); }
+        { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 7 * W, r3, e3); h3 = hit_bits(v, e, c + 3 * W); }
+        if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j * W);
+        }
+    }
+    if (qcount) spill();
+}
+hipError_t apm_launch_sieve(const ApmSieveArgs &a, int n_cu, hipStream_t s) {
+    if (a.nchunks <= 0) return hipSuccess;
+    const int64_t want = (a.nchunks + 3) / 4;
+    const int64_t cap = (int64_t)n_cu * 5; // = the kernel's launch bound
+    const int64_t nb = want < cap ? want : cap;
+    ApmSieveArgs args = a;
+    if (const char *e = getenv("APM_FILTER_ABLATE")) args.ablate = atoi(e); // measurement aid, results invalid
+    void *kargs[] = {&args};
+    return hipLaunchKernel((const void *)apm_sieve_kernel, dim3((unsigned)nb), dim3(APM_BLOCK), kargs, 8192 + 4 * 256 * 8, s);
 }
 
 static size_t apm_stream_lds_bytes(const ApmFilterArgs &a) {
@@ -1571,7 +1700,7 @@ hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t
     if (a.ntiles <= 0 || a.n_pats <= 0) return hipSuccess;
     const void *fn = apm_stream_fn(a.band, a.key_len, a.stride);
     if (!fn) return hipErrorInvalidValue;
-    const int64_t want = (a.ntiles + 3) / 4;
+    const int64_t want = a.cand_mode == 1 ? max_blocks : (a.ntiles + 3) / 4; // (verify-only: list length unknown here)
     const int64_t cap = max_blocks < 1 ? 1 : max_blocks;
     const int64_t nb = want < cap ? want : cap;
     ApmFilterArgs args = a;

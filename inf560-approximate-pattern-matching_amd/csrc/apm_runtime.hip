@@ -69,10 +69,18 @@ struct TiledLaunch {       // host description of one tiled scan launch
     int o_bmp = 0, code_shift = 1; // per-position classes: key bitmap over 2-bit byte codes (leads the image)
     int o_pat = 0;                 // pattern bytes inside the image
     int key_len = 0, stride = 0;      // BANDED: (16,16), (8,8) or (8,1)
+    bool sieved = false;              // BANDED per-position launch fed by the shared sieve pass (ctx->sieve)
     int nb = 0, lg_nb = 0, qcap = 0;
     int a_max = 0;                    // BANDED: largest key offset
     int blocks_per_cu[3] = {0, 0, 0}; // BANDED: resident workgroups per CU (occupancy query, cached) [tile, tile+dma, stream]
     int m_max = 0, m_min = 0, tile = 0;
+};
+
+struct SievePlan {         // one text pass (apm_sieve_kernel) shared by all sparse per-position launches
+    bool on = false;
+    int code_shift = 1;
+    int m_max = 0;
+    std::vector<uint8_t> bitmap; // 8 KiB over 8-byte code words
 };
 
 struct GenericGroup {      // patterns scanned by the generic kernel, one launch (grid.y = pattern)
@@ -106,6 +114,9 @@ struct DeviceState {
     unsigned long long pos_cap = 0;
     uint8_t *d_text = nullptr;
     size_t text_cap = 0;
+    uint8_t *d_sieve_bmp = nullptr;            // sieve bitmap (8 KiB)
+    unsigned long long *d_cand = nullptr;      // sieve candidate list: [0] = counter, [1..] = positions
+    unsigned long long cand_cap = 0;
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
     bool events_recorded = false;
     // per-call accounting
@@ -130,6 +141,7 @@ struct apm_ctx {
     std::vector<DeviceState> devs;
     std::vector<PatternInfo> pats;
     std::vector<TiledLaunch> tiled;
+    SievePlan sieve;
     GenericGroup tails;   // tiled-kernel patterns with m > 128: tails by the generic kernel
     GenericGroup stails;  // tiled-kernel patterns with m <= 128: tails by the bit-vector tail kernel
     GenericGroup longs;   // patterns scanned fully by the generic kernel
@@ -225,6 +237,7 @@ void free_device_plan(DeviceState &ds) {
     if (ds.d_stail_descs) hipFree(ds.d_stail_descs), ds.d_stail_descs = nullptr;
     if (ds.d_long_descs) hipFree(ds.d_long_descs), ds.d_long_descs = nullptr;
     if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
+    if (ds.d_sieve_bmp) hipFree(ds.d_sieve_bmp), ds.d_sieve_bmp = nullptr;
 }
 
 template <typename T>
@@ -354,6 +367,27 @@ int build_plan(apm_ctx *ctx) {
         }
     }
 
+    // ---- sieve decision: if the per-position classes with 6..14-byte pieces are sparse (few keys per
+    // 4^key_len code words) and the band is narrow, ONE sieve pass over the text feeds all of them, and the
+    // patterns with longer pieces join the 8-byte per-position class (one key per piece instead of a
+    // sampled family, tested at every position anyway) so that no separate pass remains for them.
+    // APM_SIEVE=0 switches it off (A/B aid). ----
+    ctx->sieve = SievePlan();
+    {
+        static const int sieve_env = getenv("APM_SIEVE") ? atoi(getenv("APM_SIEVE")) : 1;
+        long n8 = 0, n6 = 0, n_long = 0;
+        bool has_s1 = false;
+        for (int i = 0; i < P; ++i) {
+            if (ctx->pats[i].kernel != APM_KERNEL_BANDED) continue;
+            const int piece = ctx->pats[i].m / (ctx->k + 1);
+            if (piece >= 15) n_long += ctx->k + 1;
+            else if (piece >= 8) n8 += ctx->k + 1, has_s1 = true;
+            else if (piece >= 6) n6 += ctx->k + 1, has_s1 = true;
+        }
+        const double rate = (double)(n8 + n_long) / 65536.0 + (double)n6 / 4096.0;
+        ctx->sieve.on = sieve_env && has_s1 && ctx->k / 2 <= 1 && rate < 1.0 / 200.0;
+    }
+
     // ---- BANDED launches: patterns grouped by (key length, sampling stride); k+1 pigeonhole pieces each ----
     for (int cls = 0; cls < 5; ++cls) {
         static const int kl_of[5] = {16, 8, 8, 6, 4}, st_of[5] = {16, 8, 1, 1, 1};
@@ -361,6 +395,7 @@ int build_plan(apm_ctx *ctx) {
         const int stride = st_of[cls];
         auto class_of = [&](int m) {
             const int piece = m / (ctx->k + 1);
+            if (ctx->sieve.on && piece >= 8) return 2;
             return piece >= 31 ? 0 : (piece >= 15 ? 1 : (piece >= 8 ? 2 : (piece >= 6 ? 3 : 4)));
         };
         std::vector<int> idx;
@@ -378,6 +413,7 @@ int build_plan(apm_ctx *ctx) {
             L.kind = APM_KERNEL_BANDED;
             L.key_len = klen;
             L.stride = stride;
+            L.sieved = ctx->sieve.on && (cls == 2 || cls == 3);
             L.qcap = stride == 1 ? 1024 : 512;
             memset(L.lut, 0, sizeof L.lut);
             const int pieces = ctx->k + 1;
@@ -525,6 +561,38 @@ int build_plan(apm_ctx *ctx) {
         }
     }
 
+    // ---- sieve bitmap: every key of the sieved launches, as 8-byte code words under ONE code shift ----
+    if (ctx->sieve.on) {
+        SievePlan &S = ctx->sieve;
+        long best = -1;
+        for (int sft = 0; sft < 7; ++sft) {
+            long hist[4] = {0, 0, 0, 0};
+            for (const TiledLaunch &L : ctx->tiled)
+                if (L.sieved)
+                    for (const ApmPatDesc &dd : L.descs)
+                        for (uint32_t y = 0; y < dd.m; ++y) ++hist[(L.bytes[dd.byte_off + y] >> sft) & 3];
+            const long score = std::min(std::min(hist[0], hist[1]), std::min(hist[2], hist[3])) * 4 +
+                               (hist[0] > 0) + (hist[1] > 0) + (hist[2] > 0) + (hist[3] > 0) + (sft == 1);
+            if (score > best) { best = score; S.code_shift = sft; }
+        }
+        S.bitmap.assign(8192, 0);
+        for (const TiledLaunch &L : ctx->tiled) {
+            if (!L.sieved) continue;
+            S.m_max = std::max(S.m_max, L.m_max);
+            for (const ApmKey &kk : L.keys) {
+                const ApmPatDesc &dd = L.descs[kk.pat];
+                uint32_t x = 0;
+                for (int z = 0; z < L.key_len; ++z)
+                    x |= (uint32_t)((L.bytes[dd.byte_off + kk.off + z] >> S.code_shift) & 3) << (2 * z);
+                const uint32_t n_ext = 1u << (16 - 2 * L.key_len); // shorter keys: all extensions of the code word
+                for (uint32_t ext = 0; ext < n_ext; ++ext) {
+                    const uint32_t xx = x | (ext << (2 * L.key_len));
+                    S.bitmap[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
+                }
+            }
+        }
+    }
+
     // ---- upload to every device ----
     for (auto &ds : ctx->devs) {
         free_device_plan(ds);
@@ -535,6 +603,7 @@ int build_plan(apm_ctx *ctx) {
         if ((rc = upload_vec(ctx, &ds.d_stail_descs, ctx->stails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_long_descs, ctx->longs.descs))) return rc;
         HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
+        if (ctx->sieve.on && (rc = upload_vec(ctx, &ds.d_sieve_bmp, ctx->sieve.bitmap))) return rc;
         ds.tiled.resize(ctx->tiled.size());
         for (size_t t = 0; t < ctx->tiled.size(); ++t) {
             const TiledLaunch &L = ctx->tiled[t];
@@ -638,6 +707,39 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     }
 
     if (ctx->timing_on) HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
+    // the sieve pass of the sparse per-position launches (needs the 16-byte aligned text the stream kernels need)
+    bool sieve_run = false;
+    if (ctx->sieve.on && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0) {
+        const int band = ctx->k / 2;
+        const int64_t avail_pad = avail + (int64_t)((16u - ((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)avail) & 15u)) & 15u);
+        const int64_t p_lo = std::max<int64_t>(0, jb - band) & ~(int64_t)15;
+        const int64_t p_hi = std::min<int64_t>(avail, je + ctx->sieve.m_max + band);
+        if (p_hi > p_lo && avail_pad >= 16) {
+            // list capacity: 1/64 of the scanned positions (3x the rate the plan admits), 64 Ki .. 64 Mi entries
+            const unsigned long long want = std::min<unsigned long long>(64ull << 20, std::max<unsigned long long>(64ull << 10, (unsigned long long)(p_hi - p_lo) / 64));
+            if (ds.cand_cap < want) {
+                if (ds.d_cand) HIP_TRY(ctx, hipFree(ds.d_cand));
+                ds.d_cand = nullptr;
+                ds.cand_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&ds.d_cand, (size_t)(want + 2) * 8));
+                ds.cand_cap = want;
+            }
+            HIP_TRY(ctx, hipMemsetAsync(ds.d_cand, 0, 16, ds.stream));
+            ApmSieveArgs sv{};
+            sv.text = d_text;
+            sv.avail_pad = avail_pad;
+            sv.tile0 = p_lo;
+            sv.nchunks = (p_hi - p_lo + 1023) / 1024;
+            sv.bitmap = reinterpret_cast<const uint4 *>(ds.d_sieve_bmp);
+            sv.code_shift = ctx->sieve.code_shift;
+            sv.cand = ds.d_cand + 2;
+            sv.cand_n = ds.d_cand;
+            sv.cand_cap = ds.cand_cap;
+            HIP_TRY(ctx, apm_launch_sieve(sv, ds.n_cu, ds.stream));
+            ds.launches++;
+            sieve_run = true;
+        }
+    }
     for (size_t t = 0; t < ctx->tiled.size(); ++t) {
         const TiledLaunch &L = ctx->tiled[t];
         const int64_t je_l = std::min<int64_t>(je, nrel - L.m_min + 1);
@@ -692,8 +794,9 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             // per-position classes stream only when candidates are expected to be rare (verification then
             // reads global text, dense 64-candidate batches); APM_FILTER_STREAM=2 forces, 3 forbids (A/B aid)
             const double hit_rate = (double)L.keys.size() / (double)(1ull << (2 * std::min(L.key_len, 8)));
-            const bool stream_ok = L.stride > 1 || (f.band <= 1 && (stream_env == 2 || (stream_env != 3 && hit_rate < 1.0 / 200.0)));
-            if (stream_env && stream_ok && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
+            const bool sieved = sieve_run && L.sieved;
+            const bool stream_ok = sieved || L.stride > 1 || (f.band <= 1 && (stream_env == 2 || (stream_env != 3 && hit_rate < 1.0 / 200.0)));
+            if ((stream_env || sieved) && stream_ok && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
                 // wave-autonomous streaming kernel over 1 KiB chunks
                 const int64_t p_lo = std::max<int64_t>(0, jb - f.band) & ~(int64_t)15;
                 const int64_t p_hi = std::min<int64_t>(avail, je_l + L.m_max + f.band);
@@ -704,6 +807,16 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                     f.n_tail = (int)ctx->stails.descs.size();
                     f.tail = ta;
                     tails_pending = false;
+                }
+                if (sieved) { // verify-only over the sieve's list, then the guarded fallback (a no-op unless the list overflowed)
+                    f.cand = ds.d_cand + 2;
+                    f.cand_n = ds.d_cand;
+                    f.cand_cap = ds.cand_cap;
+                    f.cand_mode = 1;
+                    HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
+                    ds.launches++;
+                    f.n_tail = 0; // (the tail workgroups ran with the launch above)
+                    f.cand_mode = 2;
                 }
                 HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
                 ds.launches++;
@@ -1049,6 +1162,7 @@ void apm_destroy(apm_ctx *ctx) {
         free_device_plan(ds);
         if (ds.d_scratch) hipFree(ds.d_scratch);
         if (ds.d_text) hipFree(ds.d_text);
+        if (ds.d_cand) hipFree(ds.d_cand);
         for (hipEvent_t e : {ds.ev_start, ds.ev_kstart, ds.ev_mstart, ds.ev_mstop, ds.ev_stop}) if (e) hipEventDestroy(e);
         if (ds.own_stream) hipStreamDestroy(ds.own_stream);
     }
