@@ -716,8 +716,10 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         const int64_t p_hi = std::min<int64_t>(avail, je + ctx->sieve.m_max + band);
         if (p_hi > p_lo && avail_pad >= 16) {
             // list capacity: 1/64 of the scanned positions (3x the rate the plan admits), 64 Ki .. 64 Mi entries
-            const unsigned long long want = std::min<unsigned long long>(64ull << 20, std::max<unsigned long long>(64ull << 10, (unsigned long long)(p_hi - p_lo) / 64));
-            if (ds.cand_cap < want) {
+            unsigned long long want = std::min<unsigned long long>(64ull << 20, std::max<unsigned long long>(64ull << 10, (unsigned long long)(p_hi - p_lo) / 64));
+            static const long cap_env = getenv("APM_SIEVE_CAP") ? atol(getenv("APM_SIEVE_CAP")) : 0; // test hook: force the overflow fallback
+            if (cap_env > 0) want = (unsigned long long)cap_env;
+            if (ds.cand_cap != want && (ds.cand_cap < want || cap_env > 0)) {
                 if (ds.d_cand) HIP_TRY(ctx, hipFree(ds.d_cand));
                 ds.d_cand = nullptr;
                 ds.cand_cap = 0;

@@ -586,7 +586,8 @@ print(json.dumps(out))
 
 @pytest.mark.parametrize("env", [{}, {"APM_FILTER_STREAM": "0"}, {"APM_FILTER_STREAM": "2"}, {"APM_FILTER_STREAM": "3"},
                                  {"APM_FILTER_DMA": "0"}, {"APM_FILTER_STREAM": "2", "APM_FILTER_DMA": "0"},
-                                 {"APM_SIEVE": "0"}, {"APM_SIEVE": "0", "APM_FILTER_STREAM": "2"}],
+                                 {"APM_SIEVE": "0"}, {"APM_SIEVE": "0", "APM_FILTER_STREAM": "2"},
+                                 {"APM_SIEVE_CAP": "16"}],  # candidate list overflows -> guarded fallback scans
                          ids=lambda e: ",".join("%s=%s" % (k[4:], v) for k, v in e.items()) or "default")
 def test_every_filter_kernel_form_agrees_with_oracle(env):
     """The BANDED path picks between the LDS-tile kernel (LDS-DMA or register-staged) and the wave-autonomous

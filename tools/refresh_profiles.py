@@ -9,7 +9,10 @@ pairs = [("bench_cfg2.json", "bench_cfg2_full.json"), ("prof_cfg2/trace_kernel_s
          ("pmc_fetch/pmc_counter_collection.csv", "bench_cfg2_pmc_FETCH_SIZE.csv"),
          ("pmc_write/pmc_counter_collection.csv", "bench_cfg2_pmc_WRITE_SIZE.csv"),
          ("bench_cfg3.json", "bench_cfg3_1GiB.json"), ("bench_cfg4.json", "bench_cfg4_pergpu_1GiB.json"),
-         ("bench_cfg5.json", "bench_cfg5_pergpu_1GiB.json")]
+         ("bench_cfg5.json", "bench_cfg5_pergpu_1GiB.json"),
+         ("trace_cfg3/t_kernel_stats.csv", "tool_cfg3_1GiB_kernel_stats.csv"),
+         ("trace_cfg4/t_kernel_stats.csv", "tool_cfg4_1GiB_kernel_stats.csv"),
+         ("trace_cfg5/t_kernel_stats.csv", "tool_cfg5_1GiB_kernel_stats.csv")]
 for src, dst in pairs:
     if os.path.exists(os.path.join(G, src)):
         shutil.copyfile(os.path.join(G, src), os.path.join(P, dst))
