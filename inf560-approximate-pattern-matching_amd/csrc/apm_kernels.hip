@@ -901,6 +901,10 @@ void apm_filter_kernel(ApmFilterArgs a) {
     };
 
     const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
+    // resident slot of this workgroup on its CU (workgroups b, b+256, b+512, ... share a CU on the 256-CU part;
+    // a heuristic, only the spread of the verification over the SIMDs depends on it): slots 0,1,2,3 -> 0,2,1,3
+    const int slot_on_cu = (int)(blockIdx.x >> 8);
+    const int rot0 = 2 * slot_on_cu + (slot_on_cu >> 1);
 
     // filter + enqueue, barrier, cooperative verification of tile t held in s_tile
     // filter + enqueue of the tile held in s_tile: pushes (tag, position) into queue array `qa`
@@ -971,7 +975,11 @@ void apm_filter_kernel(ApmFilterArgs a) {
 
     // cooperative verification of the candidates queued for tile t (held in s_tile); the queue must be
     // complete (a barrier since its filter)
-    auto verify_tile = [&](const uint8_t *s_tile, int t, int qa, int qc) __attribute__((always_inline)) {
+    auto verify_tile = [&](const uint8_t *s_tile, int t, int qa, int qc, int rot) __attribute__((always_inline)) {
+        // queue entries are dealt to the waves starting at wave `rot` (rotates per tile and workgroup): a short
+        // queue keeps one wave busy, and wave i of every resident workgroup sits on SIMD i -- without the
+        // rotation the verification of the whole CU would pile up on SIMD 0
+        const uint32_t vtid = (uint32_t)(tid - 64 * rot) & (APM_BLOCK - 1);
         const int64_t base = a.tile0 + (int64_t)t * a.tile_w; // first window start of the tile
         const int p0 = tid * 16;
         constexpr int NF = 16 / STRIDE;
@@ -1068,7 +1076,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
         } else if (qn <= (uint32_t)a.qcap) {
             if constexpr (PAIRS) { // work item = queue entry: the cheap pair pre-check runs once per entry ...
                 if ((tid & 63) == 0) s_qn[4 + wv] = 0u; // (wave-private: LDS operations of one wave stay in order)
-                for (uint32_t wi = tid; wi < qn; wi += APM_BLOCK) {
+                for (uint32_t wi = vtid; wi < qn; wi += APM_BLOCK) {
                     const uint32_t ent = queue[wi];
                     for_each_key(ent >> 16, (int)(ent & 0xffffu), -BAND, BAND);
                 }
@@ -1080,7 +1088,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
                     dp_item(s_tile, base, (int)(e & 0xffffu), (int)(e >> 16), (int)(wi % NSH) - BAND);
                 }
             } else { // work item = (queue entry, shift): keeps all lanes busy
-                for (uint32_t wi = tid; wi < qn * NSH; wi += APM_BLOCK) {
+                for (uint32_t wi = vtid; wi < qn * NSH; wi += APM_BLOCK) {
                     const uint32_t ent = queue[wi / NSH];
                     const int dl = (int)(wi % NSH) - BAND;
                     for_each_key(ent >> 16, (int)(ent & 0xffffu), dl, dl);
@@ -1103,7 +1111,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
             filter_tile(s_tile, it & 1, it & 1);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
             if (tid == 0) s_qn[(it + 1) & 1] = 0u; // next tile's counter (read again only after the next barrier)
-            verify_tile(s_tile, t, it & 1, it & 1);
+            verify_tile(s_tile, t, it & 1, it & 1, (it + rot0) & 3);
         }
     } else {
         // one iteration: filter tile t, barrier, verify it, then land the registers `r` (tile t+G) in the
@@ -1112,7 +1120,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
             filter_tile(s_tile, it & 1, it & 1);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
             if (tid == 0) s_qn[(it + 1) & 1] = 0u; // next iteration's counter (nobody reads it before barrier B)
-            verify_tile(s_tile, t, it & 1, it & 1);
+            verify_tile(s_tile, t, it & 1, it & 1, (it + rot0) & 3);
             if (t + G < ntiles) {
                 stash(s_other, r0);
                 if (t + 3 * G < ntiles && !(a.ablate & 2)) fetch(t + 3 * G, r0);

@@ -419,8 +419,9 @@ int build_plan(apm_ctx *ctx) {
             const int pieces = ctx->k + 1;
             for (; pos < idx.size(); ++pos) {
                 const PatternInfo &pi = ctx->pats[idx[pos]];
+                static const size_t max_keys = getenv("APM_MAX_KEYS") ? (size_t)atol(getenv("APM_MAX_KEYS")) : 4096; // measurement knob
                 if (!L.descs.empty() && (L.bytes.size() + (size_t)pi.m > 16384 ||
-                                         L.keys.size() + (size_t)pieces * stride > 4096 || L.descs.size() >= 1024 ||
+                                         L.keys.size() + (size_t)pieces * stride > max_keys || L.descs.size() >= 1024 ||
                                          L.piece_off.size() + (size_t)pieces > 60000))
                     break;
                 ApmPatDesc d{};

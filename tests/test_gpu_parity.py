@@ -563,23 +563,25 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import helpers as H
 apm = H.pkg()
 rng = random.Random(20241)
-text = bytearray(rng.choice(b"ACGT") for _ in range(300000))
 out = {}
-for k in (0, 1, 3, 4):
-    pats = []
-    for m in (16, 20, 27, 30, 40, 59, 64, 100, 128):
-        o = rng.randrange(0, len(text) - m)
-        p = bytearray(text[o:o + m])
-        for _ in range(rng.randrange(0, k + 2)):          # substitutions
-            p[rng.randrange(m)] = rng.choice(b"ACGT")
-        if k >= 2 and rng.random() < 0.5:                  # one deletion + one insertion (keeps the length)
-            i, j = sorted(rng.sample(range(1, m - 1), 2))
-            del p[i]; p.insert(j, rng.choice(b"ACGT"))
-        pats.append(bytes(p))
-    with apm.ApmContext(device=0) as ctx:
-        ctx.set_patterns(pats, k)
-        out[str(k)] = dict(patterns=[p.decode() for p in pats], counts=ctx.count_buffer(bytes(text)),
-                           kernels=[ctx.pattern_kernel(i) for i in range(len(pats))])
+for name, alphabet, n in (("dna", b"ACGT", 300000), ("prose", b"etaoin shrdlucETAOIN\n.,", 200000)):
+    trng = random.Random(name)                              # the parent regenerates the text from this seed
+    text = bytearray(trng.choice(alphabet) for _ in range(n))
+    for k in (0, 1, 3, 4):
+        pats = []
+        for m in (16, 20, 27, 30, 40, 59, 64, 100, 128):
+            o = rng.randrange(0, len(text) - m)
+            p = bytearray(text[o:o + m])
+            for _ in range(rng.randrange(0, k + 2)):          # substitutions
+                p[rng.randrange(m)] = rng.choice(alphabet)
+            if k >= 2 and rng.random() < 0.5:                  # one deletion + one insertion (keeps the length)
+                i, j = sorted(rng.sample(range(1, m - 1), 2))
+                del p[i]; p.insert(j, rng.choice(alphabet))
+            pats.append(bytes(p))
+        with apm.ApmContext(device=0) as ctx:
+            ctx.set_patterns(pats, k)
+            out["%s:%d" % (name, k)] = dict(patterns=[p.decode("latin-1") for p in pats], counts=ctx.count_buffer(bytes(text)),
+                                            kernels=[ctx.pattern_kernel(i) for i in range(len(pats))])
 print(json.dumps(out))
 """
 
@@ -597,11 +599,15 @@ def test_every_filter_kernel_form_agrees_with_oracle(env):
                        capture_output=True, env=dict(os.environ, **env), timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    rng = random.Random(20241)
-    text = bytes(bytearray(rng.choice(b"ACGT") for _ in range(300000)))
-    for k, res in got.items():
-        pats = [p.encode() for p in res["patterns"]]
+    texts = {}
+    for name, alphabet, n in (("dna", b"ACGT", 300000), ("prose", b"etaoin shrdlucETAOIN\n.,", 200000)):
+        trng = random.Random(name)
+        texts[name] = bytes(bytearray(trng.choice(alphabet) for _ in range(n)))
+    assert len(got) == 8
+    for key, res in got.items():
+        name, k = key.split(":")
+        pats = [p.encode("latin-1") for p in res["patterns"]]
         for p, kern in zip(pats, res["kernels"]):
             assert kern == (4 if len(p) // (int(k) + 1) >= 4 else 3), "BANDED wherever the pieces are long enough"
-        assert res["counts"] == H.oracle_counts(text, pats, int(k), banded=True), (k, env)
+        assert res["counts"] == H.oracle_counts(texts[name], pats, int(k), banded=True), (key, env)
         assert sum(res["counts"]) >= 5
