@@ -683,6 +683,27 @@ __device__ __forceinline__ bool apm_ext1_core(uint32_t p0, uint32_t p1, uint32_t
     return (xi >> (8 * i)) == 0ull;               // one extra text byte before pattern byte i
 }
 __device__ __forceinline__ uint32_t apm_bswap(uint32_t v) { return __builtin_bswap32(v); }
+// the same for 1 <= n <= 16 on 128-bit values held as two 64-bit halves: P = 16 pattern bytes, T = 20 text
+// bytes (the form the kernels use: ONE instance serves the forward and the backward partner).  Shifts by a variable byte count are replaced by "bytes above i" masks.
+__device__ __forceinline__ bool apm_ext1_core16(const uint32_t (&p)[4], const uint32_t (&t)[5], int n) {
+    typedef unsigned long long u64;
+    const u64 Pl = ((u64)p[1] << 32) | p[0], Ph = ((u64)p[3] << 32) | p[2];
+    const u64 Tl = ((u64)t[1] << 32) | t[0], Th = ((u64)t[3] << 32) | t[2];
+    const u64 nl = n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);                          // bytes 0..min(n,8)-1
+    const u64 nh = n <= 8 ? 0ull : (n >= 16 ? ~0ull : ((1ull << (8 * (n - 8))) - 1ull)); // bytes 8..n-1
+    const u64 x0l = (Pl ^ Tl) & nl, x0h = (Ph ^ Th) & nh;
+    if ((x0l | x0h) == 0ull) return true;
+    const int i = x0l ? (__builtin_ctzll(x0l) >> 3) : 8 + (__builtin_ctzll(x0h) >> 3); // first mismatching byte
+    if (i >= n - 1) return true;
+    // masks of the bytes above i (for the substitution / missing-text-byte cases) and from i on (extra text byte)
+    const u64 gl = i + 1 < 8 ? (~0ull << (8 * (i + 1))) : 0ull, gh = i + 1 < 8 ? ~0ull : (~0ull << (8 * (i + 1 - 8)));
+    const u64 el = i < 8 ? (~0ull << (8 * i)) : 0ull, eh = i < 8 ? ~0ull : (~0ull << (8 * (i - 8)));
+    if (((x0l & gl) | (x0h & gh)) == 0ull) return true; // substitution at i
+    const u64 Tdl = Tl << 8, Tdh = (Th << 8) | (Tl >> 56); // text shifted up by one byte
+    if ((((Pl ^ Tdl) & nl & gl) | ((Ph ^ Tdh) & nh & gh)) == 0ull) return true; // pattern byte i has no text counterpart
+    const u64 Tul = (Tl >> 8) | (Th << 56), Tuh = (Th >> 8) | ((u64)t[4] << 56); // text shifted down by one byte
+    return (((Pl ^ Tul) & nl & el) | ((Ph ^ Tuh) & nh & eh)) == 0ull; // one extra text byte before pattern byte i
+}
 
 // pattern pb[pp..pp+n) vs text read FORWARD from tb[tp]: <= 1 edit, all of the pattern consumed
 __device__ __forceinline__ bool apm_ext_fwd(const uint8_t *tb, int tp, const uint8_t *pb, int pp, int n) {
@@ -733,7 +754,7 @@ __device__ __forceinline__ bool apm_ext_bwd(const uint8_t *tb, int te, const uin
 typedef __attribute__((address_space(3))) uint8_t apm_lds_u8; // LDS byte, for constant-address accesses
 
 template <int BAND, int KL, int STRIDE, int DMA>
-__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : ((BAND >= 1 && STRIDE == 1) ? (DMA ? 5 : 4) : 6)))
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 2 && STRIDE == 1 && !DMA) ? 3 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : ((BAND >= 1 && STRIDE == 1) ? (DMA ? 5 : 4) : 6))))
 void apm_filter_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;
@@ -848,12 +869,41 @@ void apm_filter_kernel(ApmFilterArgs a) {
                 if (s_tile[tq + x] != s_pat[poff + aq + x]) return false;
             const int p = q ^ 1;
             if (p >= n_pieces) return true; // unpaired last piece (even k)
+            // partner piece: after this one (p > q, text read forward from the end of the piece) or before it
+            // (read backward from its start, both strings byte-reversed); <= 16 bytes -> one 128-bit core
+            uint32_t P[4], T[5];
+            int n;
             if (p > q) {
                 const int ap1 = (p + 1 < n_pieces) ? (int)s_poff[aux + p + 1] : m;
-                return apm_ext_fwd(s_tile, tq + (aq1 - aq), s_pat, poff + aq1, ap1 - aq1);
+                n = ap1 - aq1;
+                if (n > 16) return apm_ext_fwd(s_tile, tq + (aq1 - aq), s_pat, poff + aq1, n);
+                apm_lds_dwords<4>(s_pat, poff + aq1, P);
+                apm_lds_dwords<5>(s_tile, tq + (aq1 - aq), T);
+            } else {
+                const int ap = (int)s_poff[aux + p];
+                n = aq - ap;
+                if (n > 16) return apm_ext_bwd(s_tile, tq, s_pat, poff + ap, n);
+                // a window this tile counts has tq >= front + n - band >= 14: nearer the tile start it is none,
+                // and the 20 text bytes in front of tq exist only from tq = 20 on (short partners need 9)
+                if (tq < 12 || (tq < 20 && n > 8)) return false;
+                uint32_t Q[4], W[5];
+                apm_lds_dwords<4>(s_pat, poff + aq - 16, Q);
+                const int back = tq < 20 ? 12 : 20;
+                apm_lds_dwords<5>(s_tile, tq - back, W); // bytes [tq-back, tq-back+20)
+#pragma unroll
+                for (int z = 0; z < 4; ++z) P[z] = apm_bswap(Q[3 - z]);
+                if (back == 20) {
+#pragma unroll
+                    for (int z = 0; z < 5; ++z) T[z] = apm_bswap(W[4 - z]);
+                } else { // the 12 bytes in front of tq, reversed; n <= 8 looks at 9 of them
+                    T[0] = apm_bswap(W[2]);
+                    T[1] = apm_bswap(W[1]);
+                    T[2] = apm_bswap(W[0]);
+                    T[3] = 0u;
+                    T[4] = 0u;
+                }
             }
-            const int ap = (int)s_poff[aux + p];
-            return apm_ext_bwd(s_tile, tq, s_pat, poff + ap, aq - ap);
+            return apm_ext1_core16(P, T, n);
         }
     };
 
@@ -1292,12 +1342,27 @@ void apm_stream_kernel(ApmFilterArgs a) {
                 if (apm_gbyte(text, limit, tq + x) != (int)s_pat[poff + aq + x]) return false;
             const int p = q ^ 1;
             if (p >= n_pieces) return true; // unpaired last piece (even k)
+            uint32_t P[4], T[5]; // (see apm_filter_kernel: one 128-bit core for both directions)
+            int n;
             if (p > q) {
                 const int ap1 = (p + 1 < n_pieces) ? (int)s_poff[aux + p + 1] : m;
-                return apm_ext_fwd_g(text, limit, tq + (aq1 - aq), s_pat, poff + aq1, ap1 - aq1);
+                n = ap1 - aq1;
+                if (n > 16) return apm_ext_fwd_g(text, limit, tq + (aq1 - aq), s_pat, poff + aq1, n);
+                apm_lds_dwords<4>(s_pat, poff + aq1, P);
+                apm_gdwords<5>(text, limit, tq + (aq1 - aq), T);
+            } else {
+                const int ap = (int)s_poff[aux + p];
+                n = aq - ap;
+                if (n > 16) return apm_ext_bwd_g(text, limit, tq, s_pat, poff + ap, n);
+                uint32_t Q[4], W[5];
+                apm_lds_dwords<4>(s_pat, poff + aq - 16, Q);
+                apm_gdwords<5>(text, limit, tq - 20, W);
+#pragma unroll
+                for (int z = 0; z < 4; ++z) P[z] = apm_bswap(Q[3 - z]);
+#pragma unroll
+                for (int z = 0; z < 5; ++z) T[z] = apm_bswap(W[4 - z]);
             }
-            const int ap = (int)s_poff[aux + p];
-            return apm_ext_bwd_g(text, limit, tq, s_pat, poff + ap, aq - ap);
+            return apm_ext1_core16(P, T, n);
         }
     };
 

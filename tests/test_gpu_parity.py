@@ -611,3 +611,87 @@ def test_every_filter_kernel_form_agrees_with_oracle(env):
             assert kern == (4 if len(p) // (int(k) + 1) >= 4 else 3), "BANDED wherever the pieces are long enough"
         assert res["counts"] == H.oracle_counts(texts[name], pats, int(k), banded=True), (key, env)
         assert sum(res["counts"]) >= 5
+
+
+@pytest.mark.parametrize("m,k", [(16, 3), (20, 3), (36, 3), (50, 5), (24, 2)])
+def test_edited_occurrences_at_every_offset_around_tile_seams(ctx, apm, m, k):
+    """Occurrences carrying one deletion + one insertion (so every piece shift of the band is exercised, forward
+    and backward partner pre-checks included), planted so that their starts sweep all offsets around the tile
+    kernel's tile boundaries (tile width = (4096 - 16 - m - k//2) & ~31 window starts)."""
+    rng = random.Random(1000 * m + k)
+    tile_w = (4096 - 16 - m - k // 2) & ~31
+    pat = bytes(rng.choice(b"ACGT") for _ in range(m))
+    n_occ = 150
+    text = bytearray(rng.choice(b"ACGT") for _ in range(tile_w * (n_occ + 2)))
+    for i in range(n_occ):
+        w = bytearray(pat)
+        kind = i % 5
+        if kind >= 1:  # a deletion and an insertion at varying places (distance 2, length kept)
+            a = 1 + (i * 7) % (m - 3)
+            b = 1 + (i * 11) % (m - 3)
+            if kind in (1, 2):
+                del w[min(a, b)]
+                w.insert(max(a, b), rng.choice(b"ACGT"))
+            else:
+                w.insert(min(a, b), rng.choice(b"ACGT"))
+                del w[max(a, b) + 1 if max(a, b) + 1 < len(w) else len(w) - 1]
+            if kind == 2 and k >= 3:  # plus a substitution
+                w[(i * 5) % m] = rng.choice(b"ACGT")
+        assert len(w) == m
+        pos = tile_w * (i + 1) - 75 + i  # sweeps [-75, +75) around a boundary
+        text[pos:pos + m] = w
+    text = bytes(text)
+    want = H.oracle_counts(text, [pat], k, banded=True)
+    assert want[0] >= n_occ // 2
+    for variant in ("auto", "banded"):
+        ctx.set_kernel(variant)
+        ctx.set_patterns([pat], k)
+        assert ctx.count_buffer(text) == want, (variant, m, k)
+    # unaligned text pointer -> register-staged tile kernel
+    ctx.set_kernel("auto")
+    ctx.set_patterns([pat], k)
+    d = ctx.device_alloc(len(text) + 64)
+    try:
+        ctx.device_upload(d + 3, text)
+        cnt = ctx.device_alloc(8)
+        ctx.device_memset(cnt, 0, 8)
+        ctx.count_shard_device(d + 3, 0, len(text), len(text), 0, len(text), cnt)
+        ctx.synchronize()
+        assert int.from_bytes(ctx.device_download(cnt, 8), "little") == want[0]
+        ctx.device_free(cnt)
+    finally:
+        ctx.device_free(d)
+
+
+@pytest.mark.parametrize("m", [16, 17, 19])
+def test_window_nominated_only_by_a_shifted_piece_at_tile_start(ctx, apm, m):
+    """k = 3, four pieces: the window = piece 0 with one byte deleted | piece 1 intact (hence found one position
+    early) | piece 2 with a substitution | piece 3 with an inserted byte.  Only (piece 1, shift -1) can nominate
+    it, through the BACKWARD partner pre-check, whose text bytes lie in front of the piece -- placed on the first
+    window starts of several tiles, where those bytes sit at the very beginning of the staged tile."""
+    k = 3
+    rng = random.Random(m)
+    pat = bytes(rng.choice(b"ACGT") for _ in range(m))
+    a = [q * m // 4 for q in range(5)]                     # piece offsets
+    pieces = [bytearray(pat[a[q]:a[q + 1]]) for q in range(4)]
+    del pieces[0][1]
+    other = {65: 67, 67: 71, 71: 84, 84: 65}
+    pieces[2][1] = other[pieces[2][1]]
+    pieces[3].insert(2, other[pieces[3][2]])
+    w = bytes(pieces[0] + pieces[1] + pieces[2] + pieces[3])
+    assert len(w) == m and H.window_distance(pat, w) == 3
+    tile_w = (4096 - 16 - m - k // 2) & ~31
+    text = bytearray(rng.choice(b"ACGT") for _ in range(tile_w * 12))
+    planted = []
+    for t in range(1, 11):
+        pos = tile_w * t + (t % 5)                         # window starts 0..4 of tile t
+        text[pos:pos + m] = w
+        planted.append(pos)
+    text = bytes(text)
+    want = H.oracle_counts(text, [pat], k, banded=True)
+    assert want[0] >= 10
+    for variant in ("auto", "banded", "bitpar"):
+        ctx.set_kernel(variant)
+        ctx.set_patterns([pat], k)
+        assert ctx.count_buffer(text) == want, (variant, m)
+    ctx.set_kernel("auto")
