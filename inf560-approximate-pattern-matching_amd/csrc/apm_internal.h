@@ -111,6 +111,9 @@ struct ApmFilterArgs {
     int image_len, o_tab, o_kid, o_ovf, o_kinfo, o_pinfo, o_next, o_poff; /* o_next: nk x u16 chain links,
                               o_poff: piece offsets a_q (u16), per pattern contiguous */
     int o_pat;             /* pattern bytes inside the image (0 unless a bitmap leads the image) */
+    int o_kext;            /* per-position classes, nk x u32: key byte offset in the pattern bytes | piece length << 16
+                              | partner length << 24 (31 = longer than 16) | partner side << 29 (0 none, 1 behind the
+                              piece, 2 in front of it): all the pair pre-check needs, in one LDS read */
     int o_bmp, code_shift; /* per-position classes: key presence bitmap over the 2-bit byte codes
                               (b >> code_shift) & 3 of the key_len key bytes (2^(2*key_len) bits); bit of code
                               word x lives in byte x & (NB-1), bit x >> log2(NB), NB = 2^(2*key_len-3) */

@@ -916,6 +916,50 @@ void apm_filter_kernel(ApmFilterArgs a) {
         if (!apm_key_equal<KL>(s_tile, pos, s_pat, poff + koff)) return false; // fingerprint collision
         return (bool)group_check(s_tile, kpiece, pos, (int)pinf.y, a.k + 1, (int)(pinf.x >> 16), poff);
     };
+    // the same for the per-position classes out of ONE packed record per key (a.o_kext): the whole piece in a
+    // single masked 16-byte compare, then the partner through the 128-bit core; no walk through kinfo / pinfo /
+    // piece offsets (four dependent LDS reads less on the path every candidate takes)
+    const uint32_t *s_kext = reinterpret_cast<const uint32_t *>(s_img + a.o_kext);
+    auto stage1_fast = [&](const uint8_t *s_tile, int kid, int pos) __attribute__((always_inline)) {
+        typedef unsigned long long u64;
+        const uint32_t kx = s_kext[kid];
+        const int at = (int)(kx & 0xffffu), len = (int)((kx >> 16) & 0xffu), n = (int)((kx >> 24) & 31u), side = (int)(kx >> 29);
+        uint32_t A[4], B[4];
+        apm_lds_dwords<4>(s_tile, pos, A);
+        apm_lds_dwords<4>(s_pat, at, B);
+        const u64 ml = len >= 8 ? ~0ull : ((1ull << (8 * len)) - 1ull);
+        const u64 mh = len <= 8 ? 0ull : (len >= 16 ? ~0ull : ((1ull << (8 * (len - 8))) - 1ull));
+        const u64 dl = (((u64)(A[1] ^ B[1]) << 32) | (A[0] ^ B[0])) & ml, dh = (((u64)(A[3] ^ B[3]) << 32) | (A[2] ^ B[2])) & mh;
+        if ((dl | dh) != 0ull) return false; // fingerprint collision, or the piece is not intact
+        for (int x = 16; x < len; ++x)       // (pieces beyond 16 bytes: only when long patterns joined this class)
+            if (s_tile[pos + x] != s_pat[at + x]) return false;
+        if (side == 0) return true;          // unpaired last piece (even k)
+        if (n == 31) return (bool)stage1_item(s_tile, kid, pos); // partner longer than 16 bytes: the generic walk
+        uint32_t P[4], T[5];
+        if (side == 1) {
+            apm_lds_dwords<4>(s_pat, at + len, P);
+            apm_lds_dwords<5>(s_tile, pos + len, T);
+        } else {
+            if (pos < 12 || (pos < 20 && n > 8)) return false; // see group_check
+            uint32_t Q[4], W[5];
+            apm_lds_dwords<4>(s_pat, at - 16, Q);
+            const int back = pos < 20 ? 12 : 20;
+            apm_lds_dwords<5>(s_tile, pos - back, W);
+#pragma unroll
+            for (int z = 0; z < 4; ++z) P[z] = apm_bswap(Q[3 - z]);
+            if (back == 20) {
+#pragma unroll
+                for (int z = 0; z < 5; ++z) T[z] = apm_bswap(W[4 - z]);
+            } else {
+                T[0] = apm_bswap(W[2]);
+                T[1] = apm_bswap(W[1]);
+                T[2] = apm_bswap(W[0]);
+                T[3] = 0u;
+                T[4] = 0u;
+            }
+        }
+        return apm_ext1_core16(P, T, n);
+    };
     // stage 2: banded DP of the window the nomination implies under shift dl + stateless dedup; bumps s_cnt
     auto dp_item = [&](const uint8_t *s_tile, int64_t base, int kid, int pos, int dl) __attribute__((always_inline)) {
         const uint32_t ki = s_kinfo[kid];
@@ -1045,7 +1089,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
                     // pre-check here, banded DP later: the survivors (few per wave) go to a wave-private list so
                     // that the DP runs on dense lanes, one (survivor, shift) each, instead of inside this
                     // divergent walk with the three shifts in sequence
-                    if (!stage1_item(s_tile, kid, pos)) return;
+                    if (!stage1_fast(s_tile, kid, pos)) return;
                     if (a.ablate & 16) return; // measurement aid: skip the banded DP
                     const uint32_t idx = atomicAdd(&s_qn[4 + wv], 1u);
                     if (idx < (uint32_t)SCAP) s_surv[wv * SCAP + idx] = (uint32_t)kid | ((uint32_t)pos << 16);

@@ -69,6 +69,7 @@ struct TiledLaunch {       // host description of one tiled scan launch
     int o_tab = 0, o_kid = 0, o_ovf = 0, o_kinfo = 0, o_pinfo = 0, o_next = 0, o_poff = 0;
     int o_bmp = 0, code_shift = 1; // per-position classes: key bitmap over 2-bit byte codes (leads the image)
     int o_pat = 0;                 // pattern bytes inside the image
+    int o_kext = 0;                // per-position classes: packed pre-check record per key
     int key_len = 0, stride = 0;      // BANDED: (16,16), (8,8) or (8,1)
     bool sieved = false;              // BANDED per-position launch fed by the shared sieve pass (ctx->sieve)
     int nb = 0, lg_nb = 0, qcap = 0;
@@ -564,6 +565,23 @@ int build_plan(apm_ctx *ctx) {
             for (const ApmKey &kk : L.keys) nxt.push_back(kk.next);
             L.o_next = append(nxt.data(), nxt.size() * 2);
             L.o_poff = append(L.piece_off.data(), L.piece_off.size() * 2);
+            if (stride == 1) { // one packed record per key for the pair pre-check (see ApmFilterArgs::o_kext)
+                std::vector<uint32_t> kext;
+                for (const ApmKey &kk : L.keys) {
+                    const ApmPatDesc &dd = L.descs[kk.pat];
+                    auto piece_begin = [&](int q) { return q >= pieces ? (int)dd.m : (int)L.piece_off[dd.aux_off + q]; };
+                    const int q = kk.piece, pq = q ^ 1;
+                    const uint32_t len = (uint32_t)(piece_begin(q + 1) - piece_begin(q));
+                    uint32_t side = 0, plen = 0;
+                    if (pq < pieces) {
+                        side = pq > q ? 1u : 2u;
+                        plen = (uint32_t)(piece_begin(pq + 1) - piece_begin(pq));
+                    }
+                    kext.push_back((uint32_t)(dd.byte_off + kk.off) | (std::min<uint32_t>(len, 255u) << 16) |
+                                   ((plen > 16 ? 31u : plen) << 24) | (side << 29));
+                }
+                L.o_kext = append(kext.data(), kext.size() * 4);
+            }
             ctx->tiled.push_back(std::move(L));
         }
     }
@@ -776,6 +794,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.o_poff = L.o_poff;
             f.o_bmp = L.o_bmp;
             f.o_pat = L.o_pat;
+            f.o_kext = L.o_kext;
             f.code_shift = L.code_shift;
             f.nk = (int)L.keys.size();
             f.nb = L.nb;
