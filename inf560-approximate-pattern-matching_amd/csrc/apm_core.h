@@ -107,4 +107,33 @@ APM_HD uint8_t apm_synth_byte(uint64_t i, uint64_t seed) {
     return (uint8_t)((0x54474341u >> (8 * c)) & 0xffu); /* "ACGT" little-endian */
 }
 
+/* ---------------------------------------------------------------------------
+ * One-edit extension (pair pre-check of the BANDED path): does the pattern piece P[0..n) match the text
+ * read from T[0] with at most ONE edit, all of P consumed, the far end of the text free (n-1, n or n+1
+ * text bytes used)?  1 <= n <= 16, on 128-bit values held as two 64-bit halves: p = 16 pattern bytes
+ * (byte i in bits 8i..), t = 20 text bytes.  The edit is located by the first mismatching byte i; the
+ * three ways to spend it are checked with masked compares against T, T<<8 and T>>8.
+ * Definition = the byte loops apm_ext_fwd in apm_kernels.hip (and ext1_loop in tests/host_core_test.cpp).
+ * ------------------------------------------------------------------------- */
+APM_HD int apm_ctz64(unsigned long long v) { return __builtin_ctzll(v); }
+APM_HD bool apm_ext1_core16(const uint32_t (&p)[4], const uint32_t (&t)[5], int n) {
+    typedef unsigned long long u64;
+    const u64 Pl = ((u64)p[1] << 32) | p[0], Ph = ((u64)p[3] << 32) | p[2];
+    const u64 Tl = ((u64)t[1] << 32) | t[0], Th = ((u64)t[3] << 32) | t[2];
+    const u64 nl = n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);                          // bytes 0..min(n,8)-1
+    const u64 nh = n <= 8 ? 0ull : (n >= 16 ? ~0ull : ((1ull << (8 * (n - 8))) - 1ull)); // bytes 8..n-1
+    const u64 x0l = (Pl ^ Tl) & nl, x0h = (Ph ^ Th) & nh;
+    if ((x0l | x0h) == 0ull) return true;
+    const int i = x0l ? (apm_ctz64(x0l) >> 3) : 8 + (apm_ctz64(x0h) >> 3); // first mismatching byte
+    if (i >= n - 1) return true;
+    // masks of the bytes above i (for the substitution / missing-text-byte cases) and from i on (extra text byte)
+    const u64 gl = i + 1 < 8 ? (~0ull << (8 * (i + 1))) : 0ull, gh = i + 1 < 8 ? ~0ull : (~0ull << (8 * (i + 1 - 8)));
+    const u64 el = i < 8 ? (~0ull << (8 * i)) : 0ull, eh = i < 8 ? ~0ull : (~0ull << (8 * (i - 8)));
+    if (((x0l & gl) | (x0h & gh)) == 0ull) return true; // substitution at i
+    const u64 Tdl = Tl << 8, Tdh = (Th << 8) | (Tl >> 56); // text shifted up by one byte
+    if ((((Pl ^ Tdl) & nl & gl) | ((Ph ^ Tdh) & nh & gh)) == 0ull) return true; // pattern byte i has no text counterpart
+    const u64 Tul = (Tl >> 8) | (Th << 56), Tuh = (Th >> 8) | ((u64)t[4] << 56); // text shifted down by one byte
+    return (((Pl ^ Tul) & nl & el) | ((Ph ^ Tuh) & nh & eh)) == 0ull; // one extra text byte before pattern byte i
+}
+
 #endif /* APM_CORE_H */

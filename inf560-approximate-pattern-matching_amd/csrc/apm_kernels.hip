@@ -661,58 +661,14 @@ __device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t 
 // intact piece and free at the far end.  A key hit therefore only needs the expensive window DP if
 // (a) the rest of its piece is intact and (b) its partner extends with <= 1 edit -- two short byte
 // comparisons that reject almost every random key hit.
-// 64-bit core for n <= 8: P = pattern bytes (byte i in bits 8i..), T0/T1/T2 = 12 text bytes.
-// One edit is located by the first mismatching byte i (ctz); the three ways to spend it are checked
-// with shifted compares: substitution (P vs T), pattern byte without text counterpart (P vs T<<8),
-// one extra text byte (P vs T>>8).
-__device__ __forceinline__ bool apm_ext1_core(uint32_t p0, uint32_t p1, uint32_t t0, uint32_t t1, uint32_t t2, int n) {
-    const unsigned long long mask = n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);
-    const unsigned long long P = ((unsigned long long)p1 << 32) | p0;
-    const unsigned long long T = ((unsigned long long)t1 << 32) | t0;
-    const unsigned long long x0 = (P ^ T) & mask;
-    if (x0 == 0ull) return true;
-    const int i = __builtin_ctzll(x0) >> 3;       // first mismatching byte
-    if (i >= n - 1) return true;                  // substitution at the last byte
-    const int sh = 8 * (i + 1);
-    if ((x0 >> sh) == 0ull) return true;          // substitution at i
-    const unsigned long long xd = (P ^ (T << 8)) & mask;
-    if ((xd >> sh) == 0ull) return true;          // pattern byte i has no text counterpart
-    const unsigned long long Tp = ((unsigned long long)__builtin_amdgcn_alignbyte(t2, t1, 1u) << 32) |
-                                  __builtin_amdgcn_alignbyte(t1, t0, 1u); // text shifted down by one byte
-    const unsigned long long xi = (P ^ Tp) & mask;
-    return (xi >> (8 * i)) == 0ull;               // one extra text byte before pattern byte i
-}
+// Core for partner pieces of <= 16 bytes (apm_ext1_core16 below): the one edit is located by the first
+// mismatching byte i; the three ways to spend it are checked with shifted compares: substitution (P vs T),
+// pattern byte without text counterpart (P vs T<<8), one extra text byte (P vs T>>8).  Longer partners (only
+// when long patterns joined a per-position class) take the byte loops of apm_ext_fwd / apm_ext_bwd.
 __device__ __forceinline__ uint32_t apm_bswap(uint32_t v) { return __builtin_bswap32(v); }
-// the same for 1 <= n <= 16 on 128-bit values held as two 64-bit halves: P = 16 pattern bytes, T = 20 text
-// bytes (the form the kernels use: ONE instance serves the forward and the backward partner).  Shifts by a variable byte count are replaced by "bytes above i" masks.
-__device__ __forceinline__ bool apm_ext1_core16(const uint32_t (&p)[4], const uint32_t (&t)[5], int n) {
-    typedef unsigned long long u64;
-    const u64 Pl = ((u64)p[1] << 32) | p[0], Ph = ((u64)p[3] << 32) | p[2];
-    const u64 Tl = ((u64)t[1] << 32) | t[0], Th = ((u64)t[3] << 32) | t[2];
-    const u64 nl = n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);                          // bytes 0..min(n,8)-1
-    const u64 nh = n <= 8 ? 0ull : (n >= 16 ? ~0ull : ((1ull << (8 * (n - 8))) - 1ull)); // bytes 8..n-1
-    const u64 x0l = (Pl ^ Tl) & nl, x0h = (Ph ^ Th) & nh;
-    if ((x0l | x0h) == 0ull) return true;
-    const int i = x0l ? (__builtin_ctzll(x0l) >> 3) : 8 + (__builtin_ctzll(x0h) >> 3); // first mismatching byte
-    if (i >= n - 1) return true;
-    // masks of the bytes above i (for the substitution / missing-text-byte cases) and from i on (extra text byte)
-    const u64 gl = i + 1 < 8 ? (~0ull << (8 * (i + 1))) : 0ull, gh = i + 1 < 8 ? ~0ull : (~0ull << (8 * (i + 1 - 8)));
-    const u64 el = i < 8 ? (~0ull << (8 * i)) : 0ull, eh = i < 8 ? ~0ull : (~0ull << (8 * (i - 8)));
-    if (((x0l & gl) | (x0h & gh)) == 0ull) return true; // substitution at i
-    const u64 Tdl = Tl << 8, Tdh = (Th << 8) | (Tl >> 56); // text shifted up by one byte
-    if ((((Pl ^ Tdl) & nl & gl) | ((Ph ^ Tdh) & nh & gh)) == 0ull) return true; // pattern byte i has no text counterpart
-    const u64 Tul = (Tl >> 8) | (Th << 56), Tuh = (Th >> 8) | ((u64)t[4] << 56); // text shifted down by one byte
-    return (((Pl ^ Tul) & nl & el) | ((Ph ^ Tuh) & nh & eh)) == 0ull; // one extra text byte before pattern byte i
-}
-
+// (apm_ext1_core16 lives in apm_core.h: tests/host_core_test.cpp checks it against the byte loops on the host)
 // pattern pb[pp..pp+n) vs text read FORWARD from tb[tp]: <= 1 edit, all of the pattern consumed
 __device__ __forceinline__ bool apm_ext_fwd(const uint8_t *tb, int tp, const uint8_t *pb, int pp, int n) {
-    if (n <= 8) {
-        uint32_t P[2], T[3];
-        apm_lds_dwords<2>(pb, pp, P);
-        apm_lds_dwords<3>(tb, tp, T);
-        return apm_ext1_core(P[0], P[1], T[0], T[1], T[2], n);
-    }
     int i = 0;
     while (i < n && tb[tp + i] == pb[pp + i]) ++i;
     if (i >= n - 1) return true; // no mismatch, or a single substitution at the last byte
@@ -728,12 +684,6 @@ __device__ __forceinline__ bool apm_ext_fwd(const uint8_t *tb, int tp, const uin
 }
 // pattern pb[pp..pp+n) vs text read BACKWARD from tb[te-1] (te exclusive): <= 1 edit
 __device__ __forceinline__ bool apm_ext_bwd(const uint8_t *tb, int te, const uint8_t *pb, int pp, int n) {
-    if (n <= 8) { // same core on the byte-reversed strings
-        uint32_t Q[2], W[3];
-        apm_lds_dwords<2>(pb, pp + n - 8, Q);
-        apm_lds_dwords<3>(tb, te - 12, W);
-        return apm_ext1_core(apm_bswap(Q[1]), apm_bswap(Q[0]), apm_bswap(W[2]), apm_bswap(W[1]), apm_bswap(W[0]), n);
-    }
     int i = 0;
     while (i < n && tb[te - 1 - i] == pb[pp + n - 1 - i]) ++i;
     if (i >= n - 1) return true;
@@ -1264,12 +1214,6 @@ __device__ __forceinline__ int apm_gbyte(const uint8_t *text, int64_t limit, int
 }
 // global-text versions of apm_ext_fwd / apm_ext_bwd (see there)
 __device__ __forceinline__ bool apm_ext_fwd_g(const uint8_t *text, int64_t limit, int64_t tp, const uint8_t *pb, int pp, int n) {
-    if (n <= 8) {
-        uint32_t P[2], T[3];
-        apm_lds_dwords<2>(pb, pp, P);
-        apm_gdwords<3>(text, limit, tp, T);
-        return apm_ext1_core(P[0], P[1], T[0], T[1], T[2], n);
-    }
     int i = 0;
     while (i < n && apm_gbyte(text, limit, tp + i) == (int)pb[pp + i]) ++i;
     if (i >= n - 1) return true;
@@ -1284,12 +1228,6 @@ __device__ __forceinline__ bool apm_ext_fwd_g(const uint8_t *text, int64_t limit
     return ok;
 }
 __device__ __forceinline__ bool apm_ext_bwd_g(const uint8_t *text, int64_t limit, int64_t te, const uint8_t *pb, int pp, int n) {
-    if (n <= 8) {
-        uint32_t Q[2], W[3];
-        apm_lds_dwords<2>(pb, pp + n - 8, Q);
-        apm_gdwords<3>(text, limit, te - 12, W);
-        return apm_ext1_core(apm_bswap(Q[1]), apm_bswap(Q[0]), apm_bswap(W[2]), apm_bswap(W[1]), apm_bswap(W[0]), n);
-    }
     int i = 0;
     while (i < n && apm_gbyte(text, limit, te - 1 - i) == (int)pb[pp + n - 1 - i]) ++i;
     if (i >= n - 1) return true;

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 template <int W>
@@ -47,6 +48,54 @@ int main() {
             bad++;
             if (bad < 5) printf("m=%d ref=%d d=%d d4=%d\n", m, ref, d, d4);
         }
+    }
+    // one-edit extension core vs its byte-loop definition (forward direction; the kernels feed the backward
+    // case byte-reversed into the same core)
+    {
+        auto ext1_loop = [](const unsigned char *pb, const unsigned char *tb, int n) {
+            int i = 0;
+            while (i < n && tb[i] == pb[i]) ++i;
+            if (i >= n - 1) return true; // no mismatch, or a single substitution at the last byte
+            bool ok = true;              // substitution at i
+            for (int j = i + 1; j < n && ok; ++j) ok = tb[j] == pb[j];
+            if (ok) return true;
+            ok = true;                   // pattern byte i has no text counterpart
+            for (int j = i + 1; j < n && ok; ++j) ok = tb[j - 1] == pb[j];
+            if (ok) return true;
+            ok = true;                   // one extra text byte before pattern byte i
+            for (int j = i; j < n && ok; ++j) ok = tb[j + 1] == pb[j];
+            return ok;
+        };
+        long n_true = 0;
+        for (int it = 0; it < 2000000; it++) {
+            const int n = 1 + rand() % 16;
+            const int alpha = 2 + rand() % 3;
+            unsigned char pb[16], tb[20];
+            for (int i = 0; i < 16; i++) pb[i] = 'a' + rand() % alpha;
+            for (int i = 0; i < 20; i++) tb[i] = 'a' + rand() % alpha;
+            const int mode = rand() % 5; // bias towards near matches: copy, substitution, deletion, insertion
+            if (mode >= 1) {
+                const int e = rand() % n;
+                int w = 0;
+                for (int i = 0; i < n && w < 20; i++) {
+                    if (mode == 2 && i == e) { tb[w++] = 'a' + rand() % alpha; continue; }
+                    if (mode == 3 && i == e) continue;
+                    if (mode == 4 && i == e) tb[w++] = 'a' + rand() % alpha;
+                    if (w < 20) tb[w++] = pb[i];
+                }
+                if (rand() % 4 == 0) tb[rand() % 20] = 'a' + rand() % alpha; // sometimes a second edit
+            }
+            uint32_t P[4], T[5];
+            memcpy(P, pb, 16);
+            memcpy(T, tb, 20);
+            const bool got = apm_ext1_core16(P, T, n), want = ext1_loop(pb, tb, n);
+            n_true += want;
+            if (got != want) {
+                bad++;
+                if (bad < 5) printf("ext1 n=%d got=%d want=%d\n", n, (int)got, (int)want);
+            }
+        }
+        if (n_true < 100000) { printf("ext1 test saw too few positives\n"); bad++; }
     }
     // synthetic generator: bytes are ACGT, deterministic
     for (uint64_t i = 0; i < 1000; i++) {
