@@ -735,13 +735,19 @@ void apm_filter_kernel(ApmFilterArgs a) {
     // the descriptor's num_records does the bounds check (out-of-range lanes return 0 and move no
     // data).  No other vector-memory operation lives in the tile loop, so the compiler's vmcnt
     // bookkeeping keeps the younger prefetch in flight while the older one is consumed.
+    // The descriptor is based on the 16-byte granule that holds text[0] (the bytes in front of an unaligned
+    // text pointer lie in the same allocation granule and never belong to a counted window): every lane's
+    // 16-byte load then starts on a multiple of 16 from that base, so a load is either wholly in front of the
+    // text (-> zeros) or wholly inside -- a load straddling text[0] would be dropped as a whole and lose the
+    // first bytes of an unaligned text.
+    const int text_sh = (int)(reinterpret_cast<uintptr_t>(a.text) & 15u);
     auto fetch = [&](int t, u32x4 &r0) __attribute__((always_inline)) {
-        const int64_t g = a.tile0 + (int64_t)t * a.tile_w - a.front; // >= -31
+        const int64_t g = a.tile0 + (int64_t)t * a.tile_w - a.front + text_sh; // multiple of 16, >= -32, from the granule base
         const int64_t gb = g > 0 ? g : 0;
-        const int64_t lim = a.avail_pad - gb;
+        const int64_t lim = a.avail_pad + text_sh - gb;
         const uint32_t nrec = lim <= 0 ? 0u : (lim > 0x7fffffffLL ? 0x7fffffffu : (uint32_t)lim);
         const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + gb, 0, (int)nrec, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) - text_sh + gb, 0, (int)nrec, 0x00020000);
         const uint32_t o0 = (uint32_t)((int)(g - gb) + 16 * tid); // negative wraps -> out of range -> 0
         r0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0, 0, 0);
     };

@@ -695,3 +695,65 @@ def test_window_nominated_only_by_a_shifted_piece_at_tile_start(ctx, apm, m):
         ctx.set_patterns([pat], k)
         assert ctx.count_buffer(text) == want, (variant, m)
     ctx.set_kernel("auto")
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_banded_path_soak_vs_oracle(ctx, apm, seed):
+    """Randomised soak of the BANDED path on texts spanning many tiles / chunks: small alphabets (many candidates
+    and real DP work), patterns cut from the text and edited (substitutions, deletions, insertions), every k the
+    path supports, aligned and unaligned device text, whole text and owner-computes shards."""
+    rnd = random.Random(seed)
+    for trial in range(50):
+        alpha = rnd.choice([b"ACGT", b"ACGT", b"AC", b"ACG", b"ACGTN", b"acgtACGT", bytes(range(32, 48))])
+        n = rnd.choice([5000, 12345, 20000, 33333, 50000, 81920])
+        if rnd.random() < 0.3:  # repetitive text: tandem repeats stress the dedup of shifted nominations
+            unit = bytes(rnd.choice(alpha) for _ in range(rnd.choice([3, 7, 19, 64])))
+            text = bytearray((unit * (n // len(unit) + 1))[:n])
+            for _ in range(n // 50):
+                text[rnd.randrange(n)] = rnd.choice(alpha)
+            text = bytes(text)
+        else:
+            text = bytes(rnd.choice(alpha) for _ in range(n))
+        k = rnd.choice([0, 1, 1, 2, 2, 3, 3, 4, 5, 6, 7])
+        pats = []
+        for _ in range(rnd.randint(1, 8)):
+            m = rnd.randint(4 * (k + 1), min(256, 40 * (k + 1)))
+            o = rnd.randrange(0, n - m)
+            p = bytearray(text[o:o + m])
+            for _e in range(rnd.randint(0, k + 1)):
+                r, pos = rnd.random(), rnd.randrange(len(p))
+                if r < 0.4:
+                    p[pos] = rnd.choice(alpha)
+                elif r < 0.7 and len(p) > 1:
+                    del p[pos]
+                    p.append(rnd.choice(alpha))
+                else:
+                    p.insert(pos, rnd.choice(alpha))
+                    p.pop()
+            pats.append(bytes(p))
+        want = H.oracle_counts(text, pats, k, banded=True)
+        ctx.set_kernel("banded")
+        ctx.set_patterns(pats, k)
+        assert all(ctx.pattern_kernel(i) == 4 for i in range(len(pats)))
+        mode = trial % 3
+        if mode == 0:
+            got = ctx.count_buffer(text)
+        else:  # device text at a random byte alignment, one shard or three owner-computes shards
+            shift = rnd.randrange(16) if mode == 1 else 0
+            d = ctx.device_alloc(n + 64)
+            cnt = ctx.device_alloc(8 * len(pats))
+            try:
+                ctx.device_upload(d + shift, text)
+                ctx.device_memset(cnt, 0, 8 * len(pats))
+                cuts = [0, n] if mode == 1 else [0, rnd.randrange(1, n // 2), rnd.randrange(n // 2, n - 1), n]
+                for lo, hi in zip(cuts, cuts[1:]):
+                    end = min(n, hi + 255)
+                    ctx.count_shard_device(d + shift + lo, lo, end - lo, n, lo, hi, cnt)
+                ctx.synchronize()
+                raw = ctx.device_download(cnt, 8 * len(pats))
+                got = [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(len(pats))]
+            finally:
+                ctx.device_free(cnt)
+                ctx.device_free(d)
+        assert got == want, (seed, trial, mode, k, [len(p) for p in pats], alpha)
+    ctx.set_kernel("auto")
