@@ -697,7 +697,16 @@ def test_window_nominated_only_by_a_shifted_piece_at_tile_start(ctx, apm, m):
     ctx.set_kernel("auto")
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
+def _soak_seeds(default):
+    """APM_SOAK_SEEDS=a-b widens the soak tests for a bug hunt (the suite itself runs the default seeds)."""
+    spec = os.environ.get("APM_SOAK_SEEDS")
+    if not spec:
+        return default
+    lo, hi = spec.split("-")
+    return list(range(int(lo), int(hi) + 1))
+
+
+@pytest.mark.parametrize("seed", _soak_seeds([11, 12, 13]))
 def test_banded_path_soak_vs_oracle(ctx, apm, seed):
     """Randomised soak of the BANDED path on texts spanning many tiles / chunks: small alphabets (many candidates
     and real DP work), patterns cut from the text and edited (substitutions, deletions, insertions), every k the
@@ -732,8 +741,9 @@ def test_banded_path_soak_vs_oracle(ctx, apm, seed):
                     p.pop()
             pats.append(bytes(p))
         want = H.oracle_counts(text, pats, k, banded=True)
-        ctx.set_kernel("banded")
+        ctx.set_kernel("auto")
         ctx.set_patterns(pats, k)
+        ctx.set_kernel("banded")
         assert all(ctx.pattern_kernel(i) == 4 for i in range(len(pats)))
         mode = trial % 3
         if mode == 0:
@@ -756,4 +766,64 @@ def test_banded_path_soak_vs_oracle(ctx, apm, seed):
                 ctx.device_free(cnt)
                 ctx.device_free(d)
         assert got == want, (seed, trial, mode, k, [len(p) for p in pats], alpha)
+    ctx.set_kernel("auto")
+
+
+@pytest.mark.parametrize("seed", _soak_seeds([21, 22]))
+def test_all_kernels_soak_vs_oracle(ctx, apm, seed):
+    """The same soak for AUTO (mixed kernels per pattern set, trivial and generic patterns included) and the
+    forced full-DP kernels, on device text at random alignments and over owner-computes shards."""
+    rnd = random.Random(seed)
+    for trial in range(40):
+        alpha = rnd.choice([b"ACGT", b"AC", b"ACGTN\n", bytes(range(256))])
+        n = rnd.choice([300, 4095, 4097, 9000, 20011, 40000])
+        text = bytes(rnd.choice(alpha) for _ in range(n))
+        k = rnd.choice([0, 1, 2, 3, 5, 8])
+        variant = rnd.choice(["auto", "auto", "bitpar", "wavefront", "generic"])
+        pats = []
+        for _ in range(rnd.randint(1, 6)):
+            m = rnd.choice([1, 3, 8, 16, 17, 31, 32, 33, 50, 64, 65, 100, 128])
+            if variant in ("auto", "generic", "wavefront") and rnd.random() < 0.2:
+                m = rnd.choice([129, 200, 256])
+            if variant in ("auto", "generic") and rnd.random() < 0.1:
+                m = rnd.choice([257, 400])
+            m = min(m, n // 2)
+            o = rnd.randrange(0, n - m)
+            p = bytearray(text[o:o + m])
+            for _e in range(rnd.randint(0, k + 1)):
+                r, pos = rnd.random(), rnd.randrange(len(p))
+                if r < 0.4:
+                    p[pos] = rnd.choice(alpha)
+                elif r < 0.7 and len(p) > 1:
+                    del p[pos]
+                    p.append(rnd.choice(alpha))
+                else:
+                    p.insert(pos, rnd.choice(alpha))
+                    p.pop()
+            pats.append(bytes(p))
+        pats = [p for p in pats if _supported(variant, len(p), k)]
+        if not pats:
+            continue
+        want = H.oracle_counts(text, pats, k, banded=True)
+        ctx.set_kernel("auto")      # (set_kernel re-plans the patterns already loaded: load the new ones first)
+        ctx.set_patterns(pats, k)
+        ctx.set_kernel(variant)
+        m_max = max(len(p) for p in pats)
+        shift = rnd.randrange(16)
+        d = ctx.device_alloc(n + 64)
+        cnt = ctx.device_alloc(8 * len(pats))
+        try:
+            ctx.device_upload(d + shift, text)
+            ctx.device_memset(cnt, 0, 8 * len(pats))
+            cuts = sorted({0, n} | {rnd.randrange(1, n) for _ in range(rnd.choice([0, 1, 3]))})
+            for lo, hi in zip(cuts, cuts[1:]):
+                end = min(n, hi + m_max - 1)
+                ctx.count_shard_device(d + shift + lo, lo, end - lo, n, lo, hi, cnt)
+            ctx.synchronize()
+            raw = ctx.device_download(cnt, 8 * len(pats))
+            got = [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(len(pats))]
+        finally:
+            ctx.device_free(cnt)
+            ctx.device_free(d)
+        assert got == want, (seed, trial, variant, k, shift, cuts, [len(p) for p in pats])
     ctx.set_kernel("auto")
