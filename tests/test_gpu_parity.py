@@ -307,6 +307,26 @@ def test_cfg3_4mib_vs_oracle(ctx, apm):
     assert ctx.count_buffer(text) == want
 
 
+@pytest.mark.parametrize("cfg,idx", [("cfg3", [0, 1, 3, 4, 8, 12, 20, 31]), ("cfg5", [0, 17, 101, 255]), ("cfg4", [0, 7, 15])])
+def test_baseline_sets_64mib_subset_vs_oracle(ctx, apm, cfg, idx):
+    """BASELINE pattern sets on 64 MiB of the synthetic text: the FULL set runs on the GPU (its real launch
+    structure: sieve pass, verify-only launches, dense tile class ...), a subset of the patterns is checked
+    against the multi-threaded banded oracle (the whole set would take the CPU minutes)."""
+    wl = H.workloads()
+    c = wl.CONFIGS[cfg]
+    n, k, seed = 1 << 26, c["k"], wl.seed_of(c["cid"])
+    pats, planted = wl.make_patterns(n, c["lens"], k, seed)
+    ctx.set_kernel("auto")
+    ctx.set_patterns(pats, k)
+    got = ctx.count_synthetic(n, seed)
+    text = apm.synth_fill_host(0, n, seed)
+    want = H.oracle_counts(text, [pats[i] for i in idx], k, banded=True)
+    assert [got[i] for i in idx] == want
+    for i, (o, d) in enumerate(planted):
+        if d <= k:
+            assert got[i] >= 1
+
+
 # ---------------------------------------------------------------- the C host (reference CLI contract)
 CLI = os.path.join(H.PKG_DIR, "host", "apm_parallel")
 
