@@ -1003,7 +1003,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
             }
             const uint32_t clo = pk[0] | (pk[1] << 8) | (pk[2] << 16) | (pk[3] << 24);
             const uint32_t chi = pk[4] | (pk[5] << 8);
-            constexpr int LB = 2 * KL - 3; // log2 of the bitmap's byte count
+            constexpr int LB = 13; // log2 of the bitmap's byte count: 8 KiB over 8-byte code words for every key length
             // the bitmap leads the image, and these kernels own no static LDS (tests check the build's
             // resource digest): its LDS address is a compile-time constant -> no address add per probe
             const apm_lds_u8 *bmp0 = (const apm_lds_u8 *)(uintptr_t)(NBUF * APM_FILTER_POS);
@@ -1478,7 +1478,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
         const uint32_t u = cd | (cd >> 6);
         return (u | (u >> 12)) & 0xffu;
     };
-    constexpr int LB = 2 * (KL > 8 ? 8 : KL) - 3; // log2 of the bitmap's byte count
+    constexpr int LB = 13; // log2 of the bitmap's byte count: 8 KiB over 8-byte code words for every key length
     // the bitmap leads the image = the start of dynamic LDS, and this kernel owns no static LDS (tests
     // check the build's resource digest): LDS address 0, a compile-time constant -> no address add per probe
     const apm_lds_u8 *bmp0 = (const apm_lds_u8 *)(uintptr_t)0;

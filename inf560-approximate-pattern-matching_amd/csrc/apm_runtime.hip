@@ -256,6 +256,53 @@ int upload_vec(apm_ctx *ctx, T **dptr, const std::vector<T> &v) {
     return APM_OK;
 }
 
+// Enter one per-position key into an 8 KiB presence bitmap over 8-byte code words (2-bit codes
+// (b >> shift) & 3, byte z of the window in bits 2z..): the piece itself (its first min(len, 8) bytes) must be
+// intact; what the window shows behind a piece shorter than 8 bytes is the text that follows it.  If the
+// piece's partner of the pair pre-check lies there (forward partner), only continuations that can still pass
+// the one-edit extension (apm_ext1_core16 semantics, bytes beyond the window = wildcards) are entered -- a
+// superset of what the pre-check accepts, several times smaller than "every continuation", which is what a
+// piece with its partner in front of it (or none) gets.
+// Without the pair pre-check (band 0: k <= 1) a nomination is just "the key bytes match", and the dedup of the
+// kernels relies on exactly that predicate -- so there only the key itself is entered, with every continuation.
+void mark_key_windows(std::vector<uint8_t> &bmp, const TiledLaunch &L, const ApmKey &kk, int pieces, int shift, bool pairs) {
+    const ApmPatDesc &dd = L.descs[kk.pat];
+    auto piece_begin = [&](int q) { return q >= pieces ? (int)dd.m : (int)L.piece_off[dd.aux_off + q]; };
+    auto code = [&](int y) { return (uint32_t)((L.bytes[dd.byte_off + y] >> shift) & 3); };
+    const int q = kk.piece, at = kk.off;
+    const int len = pairs ? piece_begin(q + 1) - at : L.key_len; // (stride 1: the key starts the piece)
+    const int vis = std::min(len, 8), ext = 8 - vis;
+    uint32_t x = 0;
+    for (int z = 0; z < vis; ++z) x |= code(at + z) << (2 * z);
+    const int pq = q ^ 1;
+    const bool forward = pairs && pq < pieces && pq > q;
+    const int n = forward ? piece_begin(pq + 1) - piece_begin(pq) : 0;
+    const int pa = at + len; // partner start (forward case)
+    for (uint32_t p = 0; p < (1u << (2 * ext)); ++p) {
+        bool ok = true;
+        if (forward && ext > 0) {
+            auto t = [&](int j) { return (p >> (2 * j)) & 3u; }; // visible text code j behind the piece
+            int i = 0;
+            while (i < n && i < ext && t(i) == code(pa + i)) ++i;
+            if (!(i >= ext || i >= n - 1)) {
+                ok = true; // substitution at i
+                for (int j = i + 1; j < n && j < ext && ok; ++j) ok = t(j) == code(pa + j);
+                if (!ok) {
+                    ok = true; // pattern byte i has no text counterpart
+                    for (int j = i + 1; j < n && j - 1 < ext && ok; ++j) ok = t(j - 1) == code(pa + j);
+                }
+                if (!ok) {
+                    ok = true; // one extra text byte before pattern byte i
+                    for (int j = i; j < n && j + 1 < ext && ok; ++j) ok = t(j + 1) == code(pa + j);
+                }
+            }
+        }
+        if (!ok) continue;
+        const uint32_t xx = x | (p << (2 * vis));
+        bmp[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
+    }
+}
+
 int build_plan(apm_ctx *ctx) {
     ctx->tiled.clear();
     ctx->tails = GenericGroup();
@@ -541,18 +588,8 @@ int build_plan(apm_ctx *ctx) {
                                        (hist[0] > 0) + (hist[1] > 0) + (hist[2] > 0) + (hist[3] > 0) + (sft == 1);
                     if (score > best) { best = score; L.code_shift = sft; }
                 }
-                const int kc = std::min(klen, 8); // key bytes the bitmap covers
-                const uint32_t nbytes = 1u << (2 * kc - 3);
-                std::vector<uint8_t> bmp(nbytes, 0);
-                for (const ApmKey &kk : L.keys) {
-                    const ApmPatDesc &dd = L.descs[kk.pat];
-                    uint32_t x = 0;
-                    for (int z = 0; z < kc; ++z) { // (sampled keys may run past the pattern: zero padded like the key itself)
-                        const unsigned char b = kk.off + z < (int)dd.m ? L.bytes[dd.byte_off + kk.off + z] : 0;
-                        x |= (uint32_t)((b >> L.code_shift) & 3) << (2 * z);
-                    }
-                    bmp[x & (nbytes - 1)] |= (uint8_t)(1u << (x >> (2 * kc - 3)));
-                }
+                std::vector<uint8_t> bmp(8192, 0); // over 8-byte code words whatever the key length
+                for (const ApmKey &kk : L.keys) mark_key_windows(bmp, L, kk, pieces, L.code_shift, ctx->k / 2 >= 1);
                 L.o_bmp = append(bmp.data(), bmp.size()); // = 0: a compile-time LDS address for the probes
             }
             L.o_pat = append(L.bytes.data(), L.bytes.size());
@@ -604,17 +641,7 @@ int build_plan(apm_ctx *ctx) {
         for (const TiledLaunch &L : ctx->tiled) {
             if (!L.sieved) continue;
             S.m_max = std::max(S.m_max, L.m_max);
-            for (const ApmKey &kk : L.keys) {
-                const ApmPatDesc &dd = L.descs[kk.pat];
-                uint32_t x = 0;
-                for (int z = 0; z < L.key_len; ++z)
-                    x |= (uint32_t)((L.bytes[dd.byte_off + kk.off + z] >> S.code_shift) & 3) << (2 * z);
-                const uint32_t n_ext = 1u << (16 - 2 * L.key_len); // shorter keys: all extensions of the code word
-                for (uint32_t ext = 0; ext < n_ext; ++ext) {
-                    const uint32_t xx = x | (ext << (2 * L.key_len));
-                    S.bitmap[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
-                }
-            }
+            for (const ApmKey &kk : L.keys) mark_key_windows(S.bitmap, L, kk, ctx->k + 1, S.code_shift, ctx->k / 2 >= 1);
         }
     }
 
