@@ -713,7 +713,10 @@ void apm_filter_kernel(ApmFilterArgs a) {
         return;
     }
     // LDS: [tile 0 | tile 1 | (tile 2) | launch image (pattern bytes, hash table, key/pattern records) | queue | counts]
-    constexpr int NBUF = DMA ? 3 : 2;
+    // LDS-DMA: three tile buffers; the per-position classes keep a fourth so that the tile before the current
+    // one stays intact and two tiles are verified in ONE pass (see the tile loop)
+    constexpr bool TWO_TILES = DMA && STRIDE == 1;
+    constexpr int NBUF = DMA ? (TWO_TILES ? 4 : 3) : 2;
     uint8_t *s_tile0 = smem;
     uint8_t *s_tile1 = smem + a.tile_len;
     uint8_t *s_img = smem + NBUF * APM_FILTER_POS;                       // (= a.tile_len, as a constant)
@@ -959,7 +962,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
     // filter + enqueue, barrier, cooperative verification of tile t held in s_tile
     // filter + enqueue of the tile held in s_tile: pushes (tag, position) into queue array `qa`
     // (0/1) under counter s_qn[qc]
-    auto filter_tile = [&](const uint8_t *s_tile, int qa, int qc) __attribute__((always_inline)) {
+    auto filter_tile = [&](const uint8_t *s_tile, int qa, int qc, int tile_bit) __attribute__((always_inline)) {
         const int p0 = tid * 16; // LDS offset of this lane's first position
         uint32_t *queue = s_queue + qa * a.qcap;
 
@@ -1018,19 +1021,24 @@ void apm_filter_kernel(ApmFilterArgs a) {
                 const int i = __builtin_ctz(hits);
                 hits &= hits - 1u;
                 const uint32_t idx = atomicAdd(&s_qn[qc], 1u);
-                if (idx < (uint32_t)a.qcap) queue[idx] = (uint32_t)(p0 + i);
+                if (idx < (uint32_t)a.qcap) queue[idx] = (uint32_t)(p0 + i) | ((uint32_t)tile_bit << 12);
             }
         }
     };
 
     // cooperative verification of the candidates queued for tile t (held in s_tile); the queue must be
     // complete (a barrier since its filter)
-    auto verify_tile = [&](const uint8_t *s_tile, int t, int qa, int qc, int rot) __attribute__((always_inline)) {
+    // (the queue may hold the candidates of TWO tiles: bit 12 of an entry's position says which one -- the
+    // "even" tile s_tile/t or the "odd" tile s_tile1/t1; callers with one tile pass it twice)
+    auto verify_tile = [&](const uint8_t *s_tile, int t, const uint8_t *s_tile1, int t1, int qa, int qc, int rot) __attribute__((always_inline)) {
         // queue entries are dealt to the waves starting at wave `rot` (rotates per tile and workgroup): a short
         // queue keeps one wave busy, and wave i of every resident workgroup sits on SIMD i -- without the
         // rotation the verification of the whole CU would pile up on SIMD 0
         const uint32_t vtid = (uint32_t)(tid - 64 * rot) & (APM_BLOCK - 1);
         const int64_t base = a.tile0 + (int64_t)t * a.tile_w; // first window start of the tile
+        const int64_t base1 = a.tile0 + (int64_t)t1 * a.tile_w;
+        const uint8_t *const s_tile0v = s_tile;
+        const int64_t base0v = base;
         const int p0 = tid * 16;
         constexpr int NF = 16 / STRIDE;
         const uint32_t *queue = s_queue + qa * a.qcap;
@@ -1039,7 +1047,10 @@ void apm_filter_kernel(ApmFilterArgs a) {
         // all keys whose tag matches at this sampled position (bucket ways, overflow list, chains);
         // one runtime loop = ONE inlined copy of the verification code
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        auto for_each_key = [&](uint32_t tag, int pos, int dl_lo, int dl_hi) __attribute__((always_inline)) {
+        auto for_each_key = [&](uint32_t tag, int pos13, int dl_lo, int dl_hi) __attribute__((always_inline)) {
+            const int pos = pos13 & 0xfff;
+            const uint8_t *s_tile = (pos13 & 0x1000) ? s_tile1 : s_tile0v; // (shadows: this entry's tile)
+            const int64_t base = (pos13 & 0x1000) ? base1 : base0v;
             auto handle = [&](int kid) __attribute__((always_inline)) {
                 if constexpr (PAIRS) {
                     // pre-check here, banded DP later: the survivors (few per wave) go to a wave-private list so
@@ -1048,7 +1059,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
                     if (!stage1_fast(s_tile, kid, pos)) return;
                     if (a.ablate & 16) return; // measurement aid: skip the banded DP
                     const uint32_t idx = atomicAdd(&s_qn[4 + wv], 1u);
-                    if (idx < (uint32_t)SCAP) s_surv[wv * SCAP + idx] = (uint32_t)kid | ((uint32_t)pos << 16);
+                    if (idx < (uint32_t)SCAP) s_surv[wv * SCAP + idx] = (uint32_t)kid | ((uint32_t)pos13 << 16);
                     else
                         for (int dl = dl_lo; dl <= dl_hi; ++dl) dp_item(s_tile, base, kid, pos, dl); // list full (rare)
                 } else {
@@ -1135,7 +1146,8 @@ void apm_filter_kernel(ApmFilterArgs a) {
                 const uint32_t ns = min(s_qn[4 + wv], (uint32_t)SCAP);
                 for (uint32_t wi = (uint32_t)(tid & 63); wi < ns * NSH; wi += 64) {
                     const uint32_t e = s_surv[wv * SCAP + wi / NSH];
-                    dp_item(s_tile, base, (int)(e & 0xffffu), (int)(e >> 16), (int)(wi % NSH) - BAND);
+                    const bool odd = (e >> 28) & 1u;
+                    dp_item(odd ? s_tile1 : s_tile, odd ? base1 : base, (int)(e & 0xffffu), (int)((e >> 16) & 0xfffu), (int)(wi % NSH) - BAND);
                 }
             } else { // work item = (queue entry, shift): keeps all lanes busy
                 for (uint32_t wi = vtid; wi < qn * NSH; wi += APM_BLOCK) {
@@ -1144,9 +1156,11 @@ void apm_filter_kernel(ApmFilterArgs a) {
                     for_each_key(ent >> 16, (int)(ent & 0xffffu), dl, dl);
                 }
             }
-        } else { // queue overflow: dense pass over every (sampled position, key)
-            for (int i = 0; i < NF; ++i)
-                for (int kid = 0; kid < a.nk; ++kid) verify_item(s_tile, base, kid, p0 + i * STRIDE, -BAND, BAND);
+        } else { // queue overflow: dense pass over every (sampled position, key) of the tile(s)
+            for (int half = 0; half < (t1 != t ? 2 : 1); ++half)
+                for (int i = 0; i < NF; ++i)
+                    for (int kid = 0; kid < a.nk; ++kid)
+                        verify_item(half ? s_tile1 : s_tile, half ? base1 : base, kid, p0 + i * STRIDE, -BAND, BAND);
         }
     };
 
@@ -1156,21 +1170,35 @@ void apm_filter_kernel(ApmFilterArgs a) {
             if (t + G < ntiles) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // every wave is past tile t-G now: its buffer takes tile t+2G
-            if (it >= 1 && t + 2 * G < ntiles && !(a.ablate & 2)) dma(t + 2 * G, (it + 2) % 3);
-            const uint8_t *s_tile = smem + (it % 3) * APM_FILTER_POS;
-            filter_tile(s_tile, it & 1, it & 1);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
-            if (tid == 0) s_qn[(it + 1) & 1] = 0u; // next tile's counter (read again only after the next barrier)
-            verify_tile(s_tile, t, it & 1, it & 1, (it + rot0) & 3);
+            if (it >= 1 && t + 2 * G < ntiles && !(a.ablate & 2)) dma(t + 2 * G, (it + 2) % NBUF);
+            const uint8_t *s_tile = smem + (it % NBUF) * APM_FILTER_POS;
+            if constexpr (TWO_TILES) {
+                // Dense per-position classes: the verification pass is latency bound and its lanes mostly
+                // empty, so the candidates of two consecutive tiles share ONE queue and ONE pass (the fourth
+                // buffer keeps the even tile intact while the odd one is filtered).
+                const int q = (it >> 1) & 1;
+                filter_tile(s_tile, q, q, it & 1);
+                if ((it & 1) || t + G >= ntiles) {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
+                    if (tid == 0) s_qn[q ^ 1] = 0u; // the next pair's counter (pushed to only after the next barrier)
+                    if (it & 1) verify_tile(smem + ((it - 1) % NBUF) * APM_FILTER_POS, t - G, s_tile, t, q, q, ((it >> 1) + rot0) & 3);
+                    else verify_tile(s_tile, t, s_tile, t, q, q, ((it >> 1) + rot0) & 3);
+                }
+            } else {
+                filter_tile(s_tile, it & 1, it & 1, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
+                if (tid == 0) s_qn[(it + 1) & 1] = 0u; // next tile's counter (read again only after the next barrier)
+                verify_tile(s_tile, t, s_tile, t, it & 1, it & 1, (it + rot0) & 3);
+            }
         }
     } else {
         // one iteration: filter tile t, barrier, verify it, then land the registers `r` (tile t+G) in the
         // other buffer and refill them with tile t+3G
         auto iteration = [&](int it, int t, const uint8_t *s_tile, uint8_t *s_other, u32x4 &r0) __attribute__((always_inline)) {
-            filter_tile(s_tile, it & 1, it & 1);
+            filter_tile(s_tile, it & 1, it & 1, 0);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // A: queue complete (LDS only)
             if (tid == 0) s_qn[(it + 1) & 1] = 0u; // next iteration's counter (nobody reads it before barrier B)
-            verify_tile(s_tile, t, it & 1, it & 1, (it + rot0) & 3);
+            verify_tile(s_tile, t, s_tile, t, it & 1, it & 1, (it + rot0) & 3);
             if (t + G < ntiles) {
                 stash(s_other, r0);
                 if (t + 3 * G < ntiles && !(a.ablate & 2)) fetch(t + 3 * G, r0);
@@ -1772,7 +1800,7 @@ hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t
 }
 
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a) { // always >= 4352 B, which the tail workgroups need
-    return (size_t)(a.use_dma ? 3 : 2) * (size_t)a.tile_len + (size_t)a.image_len + 2 * (size_t)a.qcap * 4 +
+    return (size_t)(a.use_dma ? (a.stride == 1 ? 4 : 3) : 2) * (size_t)a.tile_len + (size_t)a.image_len + 2 * (size_t)a.qcap * 4 +
            (size_t)((a.n_pats + 3) & ~3) * 4 + 32 + 4 * 128 * 4 + 16; // counters [8] + 4 survivor lists (SCAP = 128)
 }
 

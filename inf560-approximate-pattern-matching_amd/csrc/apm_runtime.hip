@@ -619,6 +619,16 @@ int build_plan(apm_ctx *ctx) {
                 }
                 L.o_kext = append(kext.data(), kext.size() * 4);
             }
+            if (stride == 1) {
+                // the tile kernel's LDS: 4 tile buffers + image + 2 queues + counters + survivor lists (see
+                // apm_filter_lds_bytes); a big image (cfg5: 57 KB) leaves room for two workgroups per CU only with
+                // the smaller candidate queue -- overflowing it is correct, just slow (dense pass)
+                auto lds_with = [&](int qcap) {
+                    return (size_t)4 * APM_FILTER_POS + L.image.size() + 2 * (size_t)qcap * 4 + ((L.descs.size() + 3) & ~(size_t)3) * 4 + 32 + 2048 + 16;
+                };
+                const size_t cu_lds = 160 * 1024;
+                if (cu_lds / lds_with(512) > cu_lds / lds_with(1024)) L.qcap = 512;
+            }
             ctx->tiled.push_back(std::move(L));
         }
     }
