@@ -699,8 +699,9 @@ __device__ __forceinline__ bool apm_ext_bwd(const uint8_t *tb, int te, const uin
 }
 
 // DMA = 1: tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging), three LDS
-// tile buffers, waits placed by hand (vmcnt(1): the younger tile stays in flight).  Needs a 16-byte
-// aligned text pointer.  DMA = 0: register-staged buffer loads, two LDS buffers, compiler-placed waits.
+// tile buffers (four for the per-position classes, whose candidates of two consecutive tiles are verified in
+// one pass), waits placed by hand (vmcnt(1): the younger tile stays in flight).  Needs a 16-byte aligned text
+// pointer.  DMA = 0: register-staged buffer loads, two LDS buffers, compiler-placed waits.
 typedef __attribute__((address_space(3))) uint8_t apm_lds_u8; // LDS byte, for constant-address accesses
 
 template <int BAND, int KL, int STRIDE, int DMA>
