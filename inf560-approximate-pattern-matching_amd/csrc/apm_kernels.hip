@@ -1600,19 +1600,20 @@ void apm_stream_kernel(ApmFilterArgs a) {
     } else {
         u32x4 r0, r1, r2, r3;
         uint2 e0 = make_uint2(0, 0), e1 = e0, e2 = e0, e3 = e0;
+        c *= 4; // (four neighbouring chunks per wave, as above)
         load_chunk(c, r0, e0);
-        load_chunk(c + W, r1, e1);
-        load_chunk(c + 2 * W, r2, e2);
-        load_chunk(c + 3 * W, r3, e3);
+        load_chunk(c + 1, r1, e1);
+        load_chunk(c + 2, r2, e2);
+        load_chunk(c + 3, r3, e3);
         for (; c < nch; c += 4 * W) {
             uint32_t h0, h1, h2, h3;
             { const u32x4 v = r0; const uint2 e = e0; load_chunk(c + 4 * W, r0, e0); h0 = hit_bits(v, e, c); }
-            { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 5 * W, r1, e1); h1 = hit_bits(v, e, c + W); }
-            { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 6 * W, r2, e2); h2 = hit_bits(v, e, c + 2 * W); }
-            { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 7 * W, r3, e3); h3 = hit_bits(v, e, c + 3 * W); }
+            { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 4 * W + 1, r1, e1); h1 = hit_bits(v, e, c + 1); }
+            { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 4 * W + 2, r2, e2); h2 = hit_bits(v, e, c + 2); }
+            { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 4 * W + 3, r3, e3); h3 = hit_bits(v, e, c + 3); }
             if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
 #pragma unroll 1
-                for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j * W);
+                for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j);
             }
         }
     }
@@ -1717,22 +1718,22 @@ __global__ __launch_bounds__(APM_BLOCK, 5) void apm_sieve_kernel(ApmSieveArgs a)
         }
     };
 
-    int64_t c = (int64_t)blockIdx.x * (APM_BLOCK / 64) + wv;
+    int64_t c = ((int64_t)blockIdx.x * (APM_BLOCK / 64) + wv) * 4; // four neighbouring chunks per wave
     u32x4 r0, r1, r2, r3;
     uint2 e0 = make_uint2(0, 0), e1 = e0, e2 = e0, e3 = e0;
     load_chunk(c, r0, e0);
-    load_chunk(c + W, r1, e1);
-    load_chunk(c + 2 * W, r2, e2);
-    load_chunk(c + 3 * W, r3, e3);
+    load_chunk(c + 1, r1, e1);
+    load_chunk(c + 2, r2, e2);
+    load_chunk(c + 3, r3, e3);
     for (; c < nch; c += 4 * W) {
         uint32_t h0, h1, h2, h3;
         { const u32x4 v = r0; const uint2 e = e0; load_chunk(c + 4 * W, r0, e0); h0 = hit_bits(v, e, c); }
-        { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 5 * W, r1, e1); h1 = hit_bits(v, e, c + W); }
-        { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 6 * W, r2, e2); h2 = hit_bits(v, e, c + 2 * W); }
-        { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 7 * W, r3, e3); h3 = hit_bits(v, e, c + 3 * W); }
+        { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 4 * W + 1, r1, e1); h1 = hit_bits(v, e, c + 1); }
+        { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 4 * W + 2, r2, e2); h2 = hit_bits(v, e, c + 2); }
+        { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 4 * W + 3, r3, e3); h3 = hit_bits(v, e, c + 3); }
         if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
 #pragma unroll 1
-            for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j * W);
+            for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j);
         }
     }
     if (qcount) spill();
