@@ -7,14 +7,24 @@
 One "step" = one pass of the hot path over the rank's text shard (all patterns),
 followed, for N > 1, by the RCCL all-reduce of the P partial counts.  Inputs are
 resident in HBM before the timed region (device-side synthetic generator).
-Workload at N = 1: BASELINE.json configs[1] (cfg2: 256 MB synthetic DNA, 8 patterns
-of length 32, k = 0); for N > 1 the same per-GPU shard size (weak scaling): a text
-of N x 256 MiB sharded by owner-computes ranges with an (m_max-1)-byte halo.
+
+Workload at N = 1 (the headline): BASELINE.json configs[2] = cfg3, the largest
+single-GPU configuration and the north_star workload: 1 GiB synthetic DNA, 32
+patterns of mixed length 16..128, k = 3.  For N > 1 every GPU gets the same 1 GiB
+cfg3 shard (weak scaling: a text of N GiB cut into owner-computes ranges with an
+(m_max-1)-byte halo), so the N = 1 point of a scaling run IS the headline.
+--config cfg2|cfg4|cfg5 selects another BASELINE workload (cfg4/cfg5: their
+per-GPU shard, 2^33 / 8 bytes = 1 GiB).  At N = 1 the same run also times cfg2,
+cfg4-per-GPU and cfg5-per-GPU (`per_config`), cross-checks every count vector at
+FULL size against the forced full-DP BITPAR kernel (`counts_equal_bitpar`), and
+times the reference's sequential path on the host cores (`cpu_baseline`, 1 core,
+and `cpu_baseline_all_cores`).
 
 Prints ONE JSON line (rank 0).  `value` = algorithmic window-DP cells per second,
 sum_p (n-k) * m_p^2 / wall, with bit-exact counts; `config.kernel` names the kernel
-variant that produced it; `variants` reports every full-DP kernel separately (cells
-really evaluated per second) so that the exact-shortcut number is never mistaken
+variant that produced it ('banded' = exact shortcut, it does NOT evaluate every DP
+cell); `variants` reports the full-DP kernels separately (cells really evaluated
+per second and their VALU fraction) so that the shortcut number is never mistaken
 for raw DP throughput.
 """
 import argparse
@@ -32,7 +42,11 @@ sys.path.insert(0, ROOT)
 PKG = "inf560-approximate-pattern-matching_amd"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz int32 lane-ops/s
+# integer VALU ceiling: 256 CU x 4 SIMD x 64 lanes per wave instruction / cycles per instruction x 2.4 GHz.
+# tools/valu_probe.hip measures the cycles per wave64 instruction on the box (profiles/r02/valu_probe.txt);
+# DESIGN.md section 3 states the measured figure this constant follows.
+VALU_CYCLES_PER_WAVE_INSTR = 2.0
+VALU_PEAK_LANE_OPS = 256 * 4 * 64 / VALU_CYCLES_PER_WAVE_INSTR * 2.4e9
 
 
 def parse():
@@ -40,26 +54,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="cfg2", help="workload: cfg2|cfg3|cfg4|cfg5 (per-GPU size = cfg n / its GPU count)")
+    ap.add_argument("--config", default="cfg3", help="workload: cfg3 (default, headline) | cfg2 | cfg4 | cfg5 "
+                    "(cfg4/cfg5: per-GPU shard = their 8 GiB / 8)")
     ap.add_argument("--kernel", default="auto")
     ap.add_argument("--bytes-per-gpu", type=int, default=0, help="override the per-GPU text size")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (CPU rehearsal of the N>1 path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-per-config", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(apm, wl, pats, k, seed, gpu_slice_counts_fn):
-    """The reference's sequential path timed on this box's host cores, on a bounded
-    sample (first 1 MiB of the same synthetic text, all patterns): kind "reference" =
-    oracle/_ref/apm_sequential (the reference's own sources compiled in the build
-    container), else kind "port" = oracle/liboracle.so, 1 thread."""
-    # ~8e9 DP cells (10-15 s on one core): 1 MiB for cfg2, proportionally less for heavier pattern sets
+def per_gpu_bytes(cfg_name, wl):
+    cfg = wl.CONFIGS[cfg_name]
+    return cfg["n"] // (8 if cfg_name in ("cfg4", "cfg5") else 1)
+
+
+def cpu_baseline(apm, pats, k, seed, gpu_slice_counts_fn):
+    """The reference's sequential path timed on this box's host cores, on a bounded sample (a prefix of the same
+    synthetic text, all patterns, ~8e9 DP cells = 15-25 s on one core): kind "reference" = oracle/_ref/apm_sequential
+    (the reference's own sources compiled in the build container), else kind "port" = oracle/liboracle.so, 1 thread.
+    Second leg: the same sample on ALL host cores (the oracle's position-parallel OpenMP form, the shape of
+    /root/reference/src/patterns_over_ranks.c:353-375).  Returns (one_core, all_cores)."""
     per_pos = sum(len(p) ** 2 for p in pats)
     sample = max(4096, min(1 << 20, int(8.6e9 / per_pos) & ~4095))
     m_max = max(len(p) for p in pats)
     text = apm.synth_fill_host(0, sample + m_max - 1, seed)
-    cells = float(sample) * sum(len(p) ** 2 for p in pats)
+    cells = float(sample) * per_pos
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "apm_sequential")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     out = None
@@ -69,13 +90,12 @@ def cpu_baseline(apm, wl, pats, k, seed, gpu_slice_counts_fn):
             path = f.name
         try:
             r = subprocess.run([ref_bin, str(k), path] + [p.decode("latin-1") for p in pats],
-                               capture_output=True, timeout=600)
+                               capture_output=True, timeout=900)
             mt = re.search(rb"APM done in ([0-9.]+) s", r.stdout)
             if r.returncode == 0 and mt:
                 secs = float(mt.group(1))
                 n_pos = max(0, sample - k)
-                out = dict(value=n_pos * sum(len(p) ** 2 for p in pats) / secs, unit="cells/s", cores=1,
-                           kind="reference", seconds=secs,
+                out = dict(value=n_pos * per_pos / secs, unit="cells/s", cores=1, kind="reference", seconds=secs,
                            sample="first %d bytes of the bench text (as a file), all %d patterns, k=%d, oracle/_ref/apm_sequential" % (sample, len(pats), k))
         finally:
             os.unlink(path)
@@ -87,11 +107,44 @@ def cpu_baseline(apm, wl, pats, k, seed, gpu_slice_counts_fn):
         secs = time.time() - t0
         out = dict(value=cells / secs, unit="cells/s", cores=1, kind="port", seconds=secs,
                    sample="first %d bytes of the bench text, all %d patterns, k=%d, oracle/liboracle.so literal DP" % (sample, len(pats), k))
+    # all host cores: literal DP, OpenMP over position chunks, 4x the sample so the run is not start-up bound
+    cores = int(H.oracle().oracle_max_threads())
+    big = min(1 << 22, sample * max(1, min(cores, 16) // 2))
+    text_big = text if big == sample else apm.synth_fill_host(0, big + m_max - 1, seed)
+    t0 = time.time()
+    for p in pats:
+        H.oracle().oracle_count_range_mt(text_big, len(text_big), p, len(p), k, 0, big, cores)
+    secs = time.time() - t0
+    allc = dict(value=float(big) * per_pos / secs, unit="cells/s", cores=cores, kind="port", seconds=secs,
+                sample="first %d bytes of the bench text, all %d patterns, k=%d, oracle/liboracle.so literal DP, OpenMP over positions" % (big, len(pats), k))
     # checker: GPU counts on the same slice must equal the oracle's
     want = H.oracle_counts(text, pats, k, banded=True, j_end=sample)
     got = gpu_slice_counts_fn(text, sample)
     out["slice_counts_match_gpu"] = bool(got == want)
-    return out
+    return out, allc
+
+
+def wavefront_wave_instr(lens, positions):
+    """VALU wave-instructions the WAVEFRONT kernel issues (from the gfx950 disassembly of wf_scan: 10 per lane-step +
+    6 per row of the lane, packed 16-bit = two windows per register; S = 64/Lm window pairs per sweep)."""
+    total = 0.0
+    for m in lens:
+        best = None
+        for r in (1, 2, 4):
+            lm = (m + r - 1) // r
+            if lm > 64:
+                continue
+            cost = (m + lm - 1) * (11.0 + 4.0 * r) / (64 // lm)       # the runtime's own choice of R (apm_runtime.hip)
+            if best is None or cost < best[0]:
+                best = (cost, r, lm)
+        _, r, lm = best
+        total += (m + lm - 1) * (10.0 + 6.0 * r) / (2 * (64 // lm)) * positions
+    return total          # wave-instructions for `positions` windows per pattern, one window pair per stream slot
+
+
+def bitpar_wave_instr(lens, positions):
+    """BITPAR: one window per lane, ~14 VALU per 32-row word and column (apm_core.h bp_step) + 3 for the Eq fetch."""
+    return sum(m * (14.0 * ((m + 31) // 32) + 3.0) for m in lens) * positions / 64.0
 
 
 def main():
@@ -120,100 +173,222 @@ def main():
         else:
             dist.init_process_group(backend=args.dist_backend)
 
-    cfg = wl.CONFIGS[args.config]
-    k, lens, seed = cfg["k"], cfg["lens"], wl.seed_of(cfg["cid"])
-    cfg_gpus = 8 if args.config in ("cfg4", "cfg5") else 1
-    per_gpu = args.bytes_per_gpu or cfg["n"] // cfg_gpus
-    n_total = per_gpu * world                                   # weak scaling
-    pats, planted = wl.make_patterns(n_total, lens, k, seed)
-    P = len(pats)
-    m_max = max(lens)
-
     stream = torch.cuda.Stream(device=dev)                      # one explicit HIP stream for everything
     torch.cuda.set_stream(stream)
     ctx = apm.ApmContext(device=dev_index)
     ctx.set_stream(stream.cuda_stream)                          # the library launches on torch's stream
-    ctx.set_patterns(pats, k)
-    ctx.set_kernel(args.kernel)
-    kernel_names = sorted({apm.KERNEL_NAMES[ctx.pattern_kernel(i)] for i in range(P)})
 
-    ob, oe, lo, hi = sharding.rank_shard(n_total, k, m_max, rank, world)
-    text = torch.empty(hi - lo + 16, dtype=torch.uint8, device=dev)
-    ctx.synth_fill_device(text.data_ptr(), lo, hi - lo, seed)   # inputs resident in HBM
-    # ring of count vectors: the all-reduce of step i (RCCL's own stream) overlaps the scans of the next steps
-    RING = 4
-    ring = [torch.zeros(P, dtype=torch.int64, device=dev) for _ in range(RING)]
-    pending = [None] * RING
-    counts = ring[0]
-    torch.cuda.synchronize()
+    per_gpu_max = max([args.bytes_per_gpu or per_gpu_bytes(args.config, wl)] +
+                      ([] if (world > 1 or args.no_per_config) else [per_gpu_bytes(c, wl) for c in ("cfg2", "cfg4", "cfg5")]))
+    text_buf = torch.empty(per_gpu_max + 512, dtype=torch.uint8, device=dev)   # one buffer, refilled per workload
 
-    def step(i):
-        b = i % RING
-        if pending[b] is not None:
-            pending[b].wait()                                   # buffer free again (stream-level wait)
-            pending[b] = None
-        c = ring[b]
-        c.zero_()
-        ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, c.data_ptr())
-        if world > 1:
-            if args.dist_backend == "nccl":
-                pending[b] = dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True)  # P x int64 over xGMI
-            else:
-                h = c.cpu()
-                sharding.allreduce_counts(h)
-                c.copy_(h)
-        return c
+    def measure(cfg_name, steps, warmup, with_variants):
+        """time `steps` steps of one workload; returns the result record (all ranks run it, rank 0 reports)"""
+        cfg = wl.CONFIGS[cfg_name]
+        k, lens, seed = cfg["k"], cfg["lens"], wl.seed_of(cfg["cid"])
+        per_gpu = args.bytes_per_gpu or per_gpu_bytes(cfg_name, wl)
+        n_total = per_gpu * world                               # weak scaling
+        pats, planted = wl.make_patterns(n_total, lens, k, seed)
+        P = len(pats)
+        m_max = max(lens)
+        ctx.set_kernel("auto")
+        ctx.set_patterns(pats, k)
+        ctx.set_kernel(args.kernel)
+        kernel_names = sorted({apm.KERNEL_NAMES[ctx.pattern_kernel(i)] for i in range(P)})
 
-    def drain():
-        for b in range(RING):
+        ob, oe, lo, hi = sharding.rank_shard(n_total, k, m_max, rank, world)
+        text = text_buf[: hi - lo + 16]
+        ctx.synth_fill_device(text.data_ptr(), lo, hi - lo, seed)   # inputs resident in HBM
+        # ring of count vectors: the all-reduce of step i (RCCL's own stream) overlaps the scans of the next steps
+        RING = 4
+        ring = [torch.zeros(P, dtype=torch.int64, device=dev) for _ in range(RING)]
+        pending = [None] * RING
+        counts = ring[0]
+        torch.cuda.synchronize()
+
+        def step(i):
+            b = i % RING
             if pending[b] is not None:
-                pending[b].wait()
+                pending[b].wait()                                   # buffer free again (stream-level wait)
                 pending[b] = None
+            c = ring[b]
+            c.zero_()
+            ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, c.data_ptr())
+            if world > 1:
+                if args.dist_backend == "nccl":
+                    pending[b] = dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True)  # P x int64 over xGMI
+                else:
+                    h = c.cpu()
+                    sharding.allreduce_counts(h)
+                    c.copy_(h)
+            return c
 
-    ctx.set_timing(False)       # no event records inside the timed region
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        counts = step(i)
-    drain()
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_counts = counts.cpu().tolist()
+        def drain():
+            for b in range(RING):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
 
-    # per-launch kernel duration with HIP events on the launch stream (the library brackets
-    # its scan kernels with hipEventRecord on the same stream), averaged over `steps` launches
-    ctx.set_timing(True)
-    kms = []
-    scratch = torch.zeros(P, dtype=torch.int64, device=dev)
-    for _ in range(args.steps):
-        scratch.zero_()
-        ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, scratch.data_ptr())
-        tm = ctx.timing()
-        kms.append(tm["main_kernel_ms"])
-    kernel_ms = sum(kms) / len(kms)
-    shard_bytes = tm["text_bytes"]
-    n_launch = tm["n_launches"]
+        ctx.set_timing(False)       # no event records inside the timed region
+        for i in range(warmup):
+            step(i)
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            counts = step(i)
+        drain()
+        ev1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        final_counts = counts.cpu().tolist()
 
-    counts_ok = all(c >= (1 if d <= k else 0) for c, (_, d) in zip(final_counts, planted))
-    if k == 0 and min(lens) >= 24:
-        counts_ok = counts_ok and final_counts == wl.expected_counts_k0(n_total, pats, planted, seed)
+        # per-launch kernel durations with HIP events on the launch stream (the library stamps the stream behind
+        # every scan-kernel launch), averaged over `steps` calls
+        ctx.set_timing(True)
+        scratch = torch.zeros(P, dtype=torch.int64, device=dev)
+        per_launch, step_ms = {}, []
+        order = []
+        for _ in range(steps):
+            scratch.zero_()
+            ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, scratch.data_ptr())
+            tm = ctx.timing()
+            step_ms.append(tm["main_kernel_ms"])
+            seen = {}
+            for label, ms in ctx.launch_times():
+                idx = seen.get(label, 0)
+                seen[label] = idx + 1
+                key = "%s#%d" % (label, idx) if idx else label
+                if key not in per_launch:
+                    per_launch[key] = []
+                    order.append(key)
+                per_launch[key].append(ms)
+        launches = [dict(kernel=key, ms_avg=sum(per_launch[key]) / len(per_launch[key])) for key in order]
+        kernel_ms = sum(step_ms) / len(step_ms)
+        shard_bytes = tm["text_bytes"]
+        dom = max(launches, key=lambda d: d["ms_avg"]) if launches else dict(kernel="+".join(kernel_names), ms_avg=kernel_ms)
+        for d in launches:
+            d["gbs"] = shard_bytes / (d["ms_avg"] * 1e-3) / 1e9 if d["ms_avg"] > 0 else 0.0
+
+        planted_found = all(c >= (1 if d <= k else 0) for c, (_, d) in zip(final_counts, planted))
+        exact_k0 = None
+        if k == 0 and min(lens) >= 24:
+            exact_k0 = bool(final_counts == wl.expected_counts_k0(n_total, pats, planted, seed))
+
+        cells = wl.algorithmic_cells(n_total, lens, k)
+        sec_per_step = elapsed / steps
+        achieved = shard_bytes / (dom["ms_avg"] * 1e-3) / 1e9 if dom["ms_avg"] > 0 else 0.0
+        traffic = None   # PMC-measured HBM bytes per launch of the dominant kernel (profiles/traffic.json, separate --pmc passes)
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                ent = json.load(f).get("%s:%s" % (cfg_name, "+".join(kernel_names)))
+            if ent and world == 1 and not args.bytes_per_gpu:
+                traffic = ent["traffic_bytes"]
+        except Exception:
+            traffic = None
+        rec = {
+            "workload": "%s: %s" % (cfg_name, cfg["desc"]),
+            "value": cells / sec_per_step, "unit": "cells/s", "ms_per_step": sec_per_step * 1e3,
+            "event_ms_per_step": ev_ms / steps,
+            "positions_x_patterns_per_s": float(max(0, n_total - k)) * P / sec_per_step,
+            "text_bytes_total": n_total, "text_bytes_per_gpu": per_gpu, "patterns": P,
+            "pattern_len": sorted(set(lens)), "k": k, "kernel": "+".join(kernel_names),
+            "counts": final_counts,
+            "planted_occurrences_found": bool(planted_found),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": dom["kernel"], "kernel_ms_avg": dom["ms_avg"],
+                         "algorithmic_bytes_per_launch": shard_bytes,
+                         "launches_per_step": len(launches), "launches": launches,
+                         "step_kernel_ms": kernel_ms,
+                         "step_frac": shard_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
+                         "note": "achieved = algorithmic bytes (1 HBM byte per text position per launch, SURVEY 8d) / average "
+                                 "duration of the step's dominant kernel, HIP events on the launch stream; step_frac = the same "
+                                 "bytes / all scan kernels of a step"},
+        }
+        if exact_k0 is not None:
+            rec["counts_equal_closed_form_k0"] = exact_k0
+
+        # full-DP kernel variants, reported under their own label (cells really evaluated)
+        if with_variants and world == 1:
+            variants = {}
+            positions = float(max(0, n_total - k))
+            if max(lens) <= 128:
+                # BITPAR at FULL size: every window of every pattern through the bit-vector DP; its counts pin the headline's
+                ctx.set_kernel("bitpar")
+                ms = []
+                for _ in range(2):
+                    scratch.zero_()
+                    ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, scratch.data_ptr())
+                    ms.append(ctx.timing()["main_kernel_ms"])
+                ok = scratch.cpu().tolist() == final_counts
+                t_s = ms[-1] * 1e-3
+                variants["bitpar"] = {"cells_evaluated_per_s": cells / t_s, "kernel_ms": ms[-1], "sample": "full size",
+                                      "counts_equal_headline": bool(ok),
+                                      "valu_frac": bitpar_wave_instr(lens, positions) * 64 / t_s / VALU_PEAK_LANE_OPS,
+                                      "hbm_frac": shard_bytes / t_s / 1e9 / HBM_PEAK_GBS}
+                rec["counts_equal_bitpar"] = bool(ok)
+            if max(lens) <= 256:
+                # WAVEFRONT (the kernel north_star names) on a bounded prefix sized for ~1 s: same counts as AUTO there
+                per_pos = float(sum(m * m for m in lens))
+                sl = int(min(hi - lo - (m_max - 1), max(1 << 22, (int(8e12 / per_pos)) & ~4095)))
+                ctx.set_kernel(args.kernel)
+                scratch.zero_()
+                ctx.count_shard_device(text.data_ptr(), lo, sl + m_max - 1, n_total, ob, ob + sl, scratch.data_ptr())
+                torch.cuda.synchronize()
+                ref_slice = scratch.cpu().tolist()
+                ctx.set_kernel("wavefront")
+                ms = []
+                for _ in range(2):
+                    scratch.zero_()
+                    ctx.count_shard_device(text.data_ptr(), lo, sl + m_max - 1, n_total, ob, ob + sl, scratch.data_ptr())
+                    ms.append(ctx.timing()["main_kernel_ms"])
+                t_s = ms[-1] * 1e-3
+                variants["wavefront"] = {"cells_evaluated_per_s": sl * per_pos / t_s, "kernel_ms": ms[-1],
+                                         "sample": "first %d window starts of the shard" % sl,
+                                         "counts_equal_headline": bool(scratch.cpu().tolist() == ref_slice),
+                                         "valu_frac": wavefront_wave_instr(lens, float(sl)) * 64 / t_s / VALU_PEAK_LANE_OPS,
+                                         "hbm_frac": sl / t_s / 1e9 / HBM_PEAK_GBS}
+            ctx.set_kernel(args.kernel)
+            rec["variants"] = variants
+        rec["_ctx"] = dict(pats=pats, k=k, seed=seed, P=P, n_total=n_total)
+        return rec
+
+    head = measure(args.config, args.steps, args.warmup, not args.no_variants)
+    hc = head.pop("_ctx")
+
+    cpu1 = cpu_all = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
+        def gpu_slice(text_bytes, sample):
+            t = torch.frombuffer(bytearray(text_bytes), dtype=torch.uint8).to(dev)
+            c = torch.zeros(hc["P"], dtype=torch.int64, device=dev)
+            ctx.count_shard_device(t.data_ptr(), 0, len(text_bytes), hc["n_total"], 0, sample, c.data_ptr())
+            torch.cuda.synchronize()
+            return c.cpu().tolist()
+        cpu1, cpu_all = cpu_baseline(apm, hc["pats"], hc["k"], hc["seed"], gpu_slice)
+
+    per_config = {}
+    if world == 1 and not args.no_per_config and not args.bytes_per_gpu:
+        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            if name == args.config:
+                continue
+            r = measure(name, args.steps, args.warmup, not args.no_variants)
+            r.pop("_ctx")
+            r.pop("counts")
+            per_config[name] = r
 
     if rank != 0:
         if world > 1:
@@ -221,78 +396,43 @@ def main():
             dist.destroy_process_group()
         return
 
-    cells = wl.algorithmic_cells(n_total, lens, k)
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = cells / (elapsed / args.steps)
-    achieved_gbs = shard_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None   # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, profiles/traffic.json)
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            ent = json.load(f).get("%s:%s" % (args.config, "+".join(kernel_names)))
-        if ent and world == 1 and not args.bytes_per_gpu:
-            traffic = ent["traffic_bytes"]
-    except Exception:
-        traffic = None
     line = {
         "metric": "window-DP-cells/sec",
-        "value": value,
+        "value": head["value"],
         "unit": "cells/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": "%s: %s" % (args.config, cfg["desc"]), "text_bytes_total": n_total,
-                   "text_bytes_per_gpu": per_gpu, "patterns": P, "pattern_len": sorted(set(lens)), "k": k,
-                   "kernel": "+".join(kernel_names), "partition": "text-sharded x%d, halo m_max-1, RCCL all-reduce of counts" % world},
+        "config": {"workload": head["workload"], "text_bytes_total": head["text_bytes_total"],
+                   "text_bytes_per_gpu": head["text_bytes_per_gpu"], "patterns": head["patterns"],
+                   "pattern_len": head["pattern_len"], "k": head["k"], "kernel": head["kernel"],
+                   "partition": "text-sharded x%d, halo m_max-1, RCCL all-reduce of counts" % world},
         "note": "value = algorithmic window-DP cells (sum_p (n-k)*m_p^2) per second with bit-exact counts; "
                 "config.kernel names the kernel that produced it ('banded' = exact shortcut: pigeonhole key filter + "
-                "banded verification, it does NOT evaluate every DP cell); raw full-DP throughput is under variants",
-        "positions_x_patterns_per_s": float(max(0, n_total - k)) * P / (elapsed / args.steps),
-        "counts": final_counts,
-        "counts_exact_vs_planted": bool(counts_ok),
-        "event_ms_per_step": ev_ms / args.steps,
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "+".join(kernel_names), "kernel_ms_avg": kernel_ms, "launches_per_step": n_launch,
-                     "algorithmic_bytes_per_launch": shard_bytes,
-                     "note": "1 HBM byte per text position per launch (SURVEY 8d); the full DP is integer-VALU bound, see variants[].valu_frac"},
+                "banded verification, it does NOT evaluate every DP cell); raw full-DP throughput is under variants; "
+                "counts_equal_bitpar = the headline's counts equal the full-DP BITPAR kernel's at full size",
+        "positions_x_patterns_per_s": head["positions_x_patterns_per_s"],
+        "counts": head["counts"],
+        "planted_occurrences_found": head["planted_occurrences_found"],
+        "event_ms_per_step": head["event_ms_per_step"],
+        "roofline": head["roofline"],
     }
-
-    # full-DP kernel variants, reported under their own label (cells really evaluated)
-    if not args.no_variants and world == 1:
-        variants = {}
-        for name, ops_per_cell in (("wavefront", None), ("bitpar", None)):
-            if max(lens) > {"wavefront": 256, "bitpar": 128}[name]:
-                continue
-            ctx.set_kernel(name)
-            reps = 3
-            ms = []
-            for _ in range(reps + 1):
-                scratch.zero_()
-                ctx.count_shard_device(text.data_ptr(), lo, hi - lo, n_total, ob, oe, scratch.data_ptr())
-                ms.append(ctx.timing()["main_kernel_ms"])
-            ms = ms[1:]
-            kms_v = sum(ms) / len(ms)
-            ok = scratch.cpu().tolist() == final_counts
-            variants[name] = {"cells_evaluated_per_s": cells / (kms_v * 1e-3), "kernel_ms": kms_v,
-                              "counts_equal_headline": bool(ok),
-                              "hbm_frac": shard_bytes / (kms_v * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        ctx.set_kernel(args.kernel)
-        line["variants"] = variants
-
-    if not args.no_cpu_baseline and world == 1:
-        def gpu_slice(text_bytes, sample):
-            t = torch.frombuffer(bytearray(text_bytes), dtype=torch.uint8).to(dev)
-            c = torch.zeros(P, dtype=torch.int64, device=dev)
-            ctx.count_shard_device(t.data_ptr(), 0, len(text_bytes), n_total, 0, sample, c.data_ptr())
-            torch.cuda.synchronize()
-            return c.cpu().tolist()
-        line["cpu_baseline"] = cpu_baseline(apm, wl, pats, k, seed, gpu_slice)
+    for key in ("counts_equal_bitpar", "counts_equal_closed_form_k0", "variants"):
+        if key in head:
+            line[key] = head[key]
+    if cpu1 is not None:
+        line["cpu_baseline"] = cpu1
+        line["cpu_baseline_all_cores"] = cpu_all
+    if per_config:
+        line["per_config"] = per_config
+    line["valu_peak"] = {"lane_ops_per_s": VALU_PEAK_LANE_OPS, "cycles_per_wave64_instruction": VALU_CYCLES_PER_WAVE_INSTR,
+                         "source": "tools/valu_probe.hip (profiles/r02/valu_probe.txt)"}
 
     print(json.dumps(line), flush=True)
     if world > 1:

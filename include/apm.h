@@ -173,6 +173,11 @@ int apm_count_synthetic(apm_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *count
  * apm_get_timing reports).  enabled=0 drops those records from the launch path. */
 int apm_set_timing(apm_ctx *ctx, int enabled);
 int apm_get_timing(const apm_ctx *ctx, apm_timing *out);
+/* Per-launch times of the last counting call on a single-device context (timing enabled): HIP events recorded on
+ * the launch stream right behind every scan-kernel launch.  Writes up to `max` durations (ms) and, if labels is
+ * not NULL, a static string naming each launch ("sieve", "verify", "tile", "stream", "bitpar", ...); returns the
+ * number written (>= 0) or a negative apm_status.  Synchronises with the last launch. */
+int apm_get_launch_times(const apm_ctx *ctx, int max, double *ms, const char **labels);
 /* Kernel variant AUTO (or the forced variant) resolves to for pattern i. */
 int apm_pattern_kernel(const apm_ctx *ctx, int i);
 /* Device memory helpers so that a C host needs no HIP headers. */

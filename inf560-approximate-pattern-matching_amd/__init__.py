@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
     "apm_device_count", "apm_abi_version", "apm_create", "apm_create_on_device", "apm_destroy",
     "apm_last_error", "apm_set_stream", "apm_set_patterns", "apm_set_kernel", "apm_count_buffer",
     "apm_count_file", "apm_find_buffer", "apm_count_shard_device", "apm_shard_range", "apm_synth_fill_device",
-    "apm_synth_fill_host", "apm_count_synthetic", "apm_set_timing", "apm_get_timing", "apm_pattern_kernel",
+    "apm_synth_fill_host", "apm_count_synthetic", "apm_set_timing", "apm_get_timing", "apm_get_launch_times",
+    "apm_pattern_kernel",
     "apm_device_alloc", "apm_device_free", "apm_device_upload", "apm_device_download",
     "apm_device_memset", "apm_synchronize",
 ]
@@ -87,6 +88,7 @@ def load_library():
         "apm_count_synthetic": (i32, [vp, u64, u64, c.POINTER(u64)]),
         "apm_set_timing": (i32, [vp, i32]),
         "apm_get_timing": (i32, [vp, c.POINTER(ApmTiming)]),
+        "apm_get_launch_times": (i32, [vp, i32, c.POINTER(c.c_double), c.POINTER(c.c_char_p)]),
         "apm_pattern_kernel": (i32, [vp, i32]),
         "apm_device_alloc": (i32, [vp, c.POINTER(vp), u64]),
         "apm_device_free": (i32, [vp, vp]),
@@ -224,6 +226,15 @@ class ApmContext:
         t = ApmTiming()
         self._check(self._lib.apm_get_timing(self._ctx, ctypes.byref(t)))
         return t.as_dict()
+
+    def launch_times(self, max_launches=32):
+        """[(label, ms)] of the scan-kernel launches of the last counting call (HIP events on the launch stream)"""
+        ms = (ctypes.c_double * max_launches)()
+        labels = (ctypes.c_char_p * max_launches)()
+        n = self._lib.apm_get_launch_times(self._ctx, max_launches, ms, labels)
+        if n < 0:
+            self._check(n)
+        return [((labels[i] or b"?").decode(), ms[i]) for i in range(n)]
 
     def synchronize(self):
         self._check(self._lib.apm_synchronize(self._ctx))

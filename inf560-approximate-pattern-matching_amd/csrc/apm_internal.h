@@ -126,7 +126,9 @@ struct ApmFilterArgs {
     int tile_w;            /* window starts per workgroup tile (multiple of 32) */
     int front;             /* bytes staged in front of the first window (0 or 16) */
     int tile_len;          /* bytes staged per tile: APM_FILTER_POS (one 16-byte load per lane) */
-    int ablate;            /* measurement aid (APM_FILTER_ABLATE); 0 in production */
+#ifdef APM_MEASURE
+    int skip_mask;         /* tools/ build only (libapm_hip_measure.so): stages to leave out, results invalid */
+#endif
     int use_dma;           /* 1: LDS-DMA tile path (text pointer 16-byte aligned), 0: register-staged path */
     int n_main_blocks;     /* set by the launcher: persistent scan workgroups */
     int n_tail;            /* extra workgroups, one per tail pattern (0: tails launched separately) */
@@ -152,13 +154,24 @@ struct ApmSieveArgs {
     int64_t nchunks;        /* 1 KiB chunks */
     const uint4 *bitmap;    /* 8 KiB: bit of code word x in byte x & 8191, bit x >> 13 */
     int code_shift;
-    int ablate;
+#ifdef APM_MEASURE
+    int skip_mask;
+#endif
     unsigned long long *cand;
     unsigned long long *cand_n;
     unsigned long long cand_cap;
 };
 
 #define APM_TAG_EMPTY 0x5bd1e995u
+
+/* Stage-skipping switches of the kernels exist only in the measurement build (make measure ->
+ * libapm_hip_measure.so, used by tools/): in the product build the test folds to a constant 0 and the
+ * branches vanish; no environment variable can change what the shipped library computes. */
+#ifdef APM_MEASURE
+#define APM_SKIP(a, bits) ((a).skip_mask & (bits))
+#else
+#define APM_SKIP(a, bits) 0
+#endif
 
 /* launchers (apm_kernels.hip) */
 hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t s);

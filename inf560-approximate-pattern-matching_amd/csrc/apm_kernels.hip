@@ -950,7 +950,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
     };
     auto verify_item = [&](const uint8_t *s_tile, int64_t base, int kid, int pos, int dl_lo, int dl_hi) __attribute__((always_inline)) {
         if (!stage1_item(s_tile, kid, pos)) return;
-        if (a.ablate & 16) return; // measurement aid: skip the banded DP
+        if (APM_SKIP(a, 16)) return; // (measurement build) skip the banded DP
         for (int dl = dl_lo; dl <= dl_hi; ++dl) dp_item(s_tile, base, kid, pos, dl);
     };
 
@@ -983,7 +983,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
                 if (idx < (uint32_t)a.qcap) queue[idx] = (tag << 16) | (uint32_t)pos;
             }
         };
-        if (a.ablate & 1) return; // measurement aid: skip the probes
+        if (APM_SKIP(a, 1)) return; // (measurement build) skip the probes
         const uint4 va = *reinterpret_cast<const uint4 *>(s_tile + p0);
         if constexpr (STRIDE == 16) {
             probe(apm_fp16(apm_fp8(va.x, va.y), apm_fp8(va.z, va.w)), p0);
@@ -1058,7 +1058,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
                     // that the DP runs on dense lanes, one (survivor, shift) each, instead of inside this
                     // divergent walk with the three shifts in sequence
                     if (!stage1_fast(s_tile, kid, pos)) return;
-                    if (a.ablate & 16) return; // measurement aid: skip the banded DP
+                    if (APM_SKIP(a, 16)) return; // (measurement build) skip the banded DP
                     const uint32_t idx = atomicAdd(&s_qn[4 + wv], 1u);
                     if (idx < (uint32_t)SCAP) s_surv[wv * SCAP + idx] = (uint32_t)kid | ((uint32_t)pos13 << 16);
                     else
@@ -1134,7 +1134,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
                 }
             }
         };
-        if (a.ablate & 8) { // measurement aid: skip verification
+        if (APM_SKIP(a, 8)) { // (measurement build) skip verification
         } else if (qn <= (uint32_t)a.qcap) {
             if constexpr (PAIRS) { // work item = queue entry: the cheap pair pre-check runs once per entry ...
                 if ((tid & 63) == 0) s_qn[4 + wv] = 0u; // (wave-private: LDS operations of one wave stay in order)
@@ -1171,7 +1171,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
             if (t + G < ntiles) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // every wave is past tile t-G now: its buffer takes tile t+2G
-            if (it >= 1 && t + 2 * G < ntiles && !(a.ablate & 2)) dma(t + 2 * G, (it + 2) % NBUF);
+            if (it >= 1 && t + 2 * G < ntiles && !APM_SKIP(a, 2)) dma(t + 2 * G, (it + 2) % NBUF);
             const uint8_t *s_tile = smem + (it % NBUF) * APM_FILTER_POS;
             if constexpr (TWO_TILES) {
                 // Dense per-position classes: the verification pass is latency bound and its lanes mostly
@@ -1202,7 +1202,7 @@ void apm_filter_kernel(ApmFilterArgs a) {
             verify_tile(s_tile, t, s_tile, t, it & 1, it & 1, (it + rot0) & 3);
             if (t + G < ntiles) {
                 stash(s_other, r0);
-                if (t + 3 * G < ntiles && !(a.ablate & 2)) fetch(t + 3 * G, r0);
+                if (t + 3 * G < ntiles && !APM_SKIP(a, 2)) fetch(t + 3 * G, r0);
             }
             __syncthreads(); // B
         };
@@ -1516,14 +1516,14 @@ void apm_stream_kernel(ApmFilterArgs a) {
         return __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(x, LB, 3), 1);
     };
     auto hit_bits = [&](const u32x4 &v, const uint2 &e, int64_t cc) __attribute__((always_inline)) {
-        if (a.ablate & 32) return (v.x ^ e.x) == 0x12345u ? 1u : 0u; // measurement aid: streaming skeleton only
+        if (APM_SKIP(a, 32)) return (v.x ^ e.x) == 0x12345u ? 1u : 0u; // (measurement build) streaming skeleton only
         uint32_t hits = 0;
         const uint32_t clo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
         const uint32_t chi = pack4(e.x) | (pack4(e.y) << 8);
 #pragma unroll
         for (int i = 15; i >= 0; --i) // descending: hits = hits << 1 | bit (one v_lshl_or_b32 each)
             hits = (hits << 1) | bmp_bit(i ? __builtin_amdgcn_alignbit(chi, clo, 2u * (uint32_t)i) : clo);
-        return (cc < nch && !(a.ablate & 1)) ? hits : 0u;
+        return (cc < nch && !APM_SKIP(a, 1)) ? hits : 0u;
     };
     // the hit positions of one chunk go to the wave queue, one bit per lane and round (<= 16 rounds of
     // <= 64 positions); the queue is verified as soon as it holds a wave's worth
@@ -1566,7 +1566,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
     };
     auto process = [&](const u32x4 &v, int64_t cc) __attribute__((always_inline)) {
         const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
-        const bool valid = cc < nch && !(a.ablate & 1);
+        const bool valid = cc < nch && !APM_SKIP(a, 1);
         if constexpr (STRIDE == 16) {
             probe(apm_fp16(apm_fp8(v.x, v.y), apm_fp8(v.z, v.w)), pos, valid);
         } else if constexpr (STRIDE == 8) {
@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(APM_BLOCK, 5) void apm_sieve_kernel(ApmSieveArgs a)
             const uint32_t byte = bmp0[x & 8191u];
             hits = (hits << 1) | __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(x, 13, 3), 1);
         }
-        return (cc < nch && !(a.ablate & 1)) ? hits : 0u;
+        return (cc < nch && !APM_SKIP(a, 1)) ? hits : 0u;
     };
     // hit positions are staged in a wave-private LDS queue (ballot + mbcnt, no atomics) and leave for the
     // global list 192+ at a time: one global atomic per batch, not per hit
@@ -1744,7 +1744,9 @@ hipError_t apm_launch_sieve(const ApmSieveArgs &a, int n_cu, hipStream_t s) {
     const int64_t cap = (int64_t)n_cu * 5; // = the kernel's launch bound
     const int64_t nb = want < cap ? want : cap;
     ApmSieveArgs args = a;
-    if (const char *e = getenv("APM_FILTER_ABLATE")) args.ablate = atoi(e); // measurement aid, results invalid
+#ifdef APM_MEASURE
+    if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
+#endif
     void *kargs[] = {&args};
     return hipLaunchKernel((const void *)apm_sieve_kernel, dim3((unsigned)nb), dim3(APM_BLOCK), kargs, 8192 + 4 * 256 * 8, s);
 }
@@ -1800,7 +1802,9 @@ hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t
     const int64_t nb = want < cap ? want : cap;
     ApmFilterArgs args = a;
     args.n_main_blocks = (int)nb;
-    if (const char *e = getenv("APM_FILTER_ABLATE")) args.ablate = atoi(e); // measurement aid, results invalid
+#ifdef APM_MEASURE
+    if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
+#endif
     void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)(nb + a.n_tail)), dim3(APM_BLOCK), kargs, apm_stream_lds_bytes(a), s);
 }
@@ -1855,7 +1859,9 @@ hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t
     const int64_t nb = a.ntiles < cap ? a.ntiles : cap;
     ApmFilterArgs args = a;
     args.n_main_blocks = (int)nb;
-    if (const char *e = getenv("APM_FILTER_ABLATE")) args.ablate = atoi(e); // measurement aid, results invalid
+#ifdef APM_MEASURE
+    if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
+#endif
     void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)(nb + a.n_tail)), dim3(APM_BLOCK), kargs, lds, s);
 }

@@ -32,8 +32,10 @@
 // --------------------------------------------------------------------------
 // internal kernels defined here (tiny)
 // --------------------------------------------------------------------------
-__global__ void apm_add_const_kernel(unsigned long long *counts, int idx, unsigned long long v) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&counts[idx], v);
+// k >= m: every window start matches (the DP never exceeds m); one launch adds the window count to all of them
+__global__ void apm_add_const_kernel(unsigned long long *counts, const int *idx, int n, unsigned long long v) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n) atomicAdd(&counts[idx[i]], v);
 }
 
 namespace {
@@ -107,6 +109,7 @@ struct DeviceState {
     ApmPatDesc *d_tail_descs = nullptr;       // tails of tiled-kernel patterns with m > 128 (generic kernel)
     ApmPatDesc *d_stail_descs = nullptr;      // tails of tiled-kernel patterns with m <= 128 (tail kernel)
     ApmPatDesc *d_long_descs = nullptr;       // generic full-scan patterns
+    int *d_trivial = nullptr;                 // indices of the patterns with k >= m
     std::vector<DevTiled> tiled;
     unsigned long long *d_counts = nullptr;   // P
     uint16_t *d_scratch = nullptr;
@@ -122,6 +125,12 @@ struct DeviceState {
     unsigned long long cand_cap = 0;
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
     bool events_recorded = false;
+    // per-launch event stamps (apm_get_launch_times): stamp i is recorded right behind scan launch i, so the time
+    // between two stamps is one launch as the stream saw it (the first one is measured from ev_mstart)
+    static constexpr int MAX_STAMPS = 32;
+    hipEvent_t ev_launch[MAX_STAMPS] = {};
+    const char *launch_label[MAX_STAMPS] = {};
+    int n_stamps = 0;
     // per-call accounting
     uint64_t text_bytes = 0;
     int launches = 0;
@@ -187,6 +196,17 @@ int fail(apm_ctx *ctx, int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
+// bookkeeping behind every scan-kernel launch: count it and, with timing on, stamp the stream
+int note_launch(apm_ctx *ctx, DeviceState &ds, const char *label) {
+    ds.launches++;
+    if (!ctx->timing_on || ds.n_stamps >= DeviceState::MAX_STAMPS) return APM_OK;
+    hipEvent_t &e = ds.ev_launch[ds.n_stamps];
+    if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+    HIP_TRY(ctx, hipEventRecord(e, ds.stream));
+    ds.launch_label[ds.n_stamps++] = label;
+    return APM_OK;
+}
+
 // ---------------------------------------------------------------------------
 // plan: which kernel scans which pattern, in which launch
 // ---------------------------------------------------------------------------
@@ -209,7 +229,8 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
         if (k >= m) return KERNEL_TRIVIAL;
         if (m <= APM_BANDED_MAX_M && k <= APM_BANDED_MAX_K && m / (k + 1) >= APM_BANDED_MIN_PIECE) return APM_KERNEL_BANDED;
         if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR;
-        return APM_KERNEL_GENERIC;
+        if (m <= APM_WAVEFRONT_MAX_M) return APM_KERNEL_WAVEFRONT; // long and loose (BANDED's pigeonhole pieces too short): LDS/DPP sweep
+        return APM_KERNEL_GENERIC;                                 // m > 256 only
     }
     switch (forced) {
     case APM_KERNEL_GENERIC: return APM_KERNEL_GENERIC;
@@ -243,6 +264,7 @@ void free_device_plan(DeviceState &ds) {
     if (ds.d_tail_descs) hipFree(ds.d_tail_descs), ds.d_tail_descs = nullptr;
     if (ds.d_stail_descs) hipFree(ds.d_stail_descs), ds.d_stail_descs = nullptr;
     if (ds.d_long_descs) hipFree(ds.d_long_descs), ds.d_long_descs = nullptr;
+    if (ds.d_trivial) hipFree(ds.d_trivial), ds.d_trivial = nullptr;
     if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
     if (ds.d_sieve_bmp) hipFree(ds.d_sieve_bmp), ds.d_sieve_bmp = nullptr;
 }
@@ -473,7 +495,11 @@ int build_plan(apm_ctx *ctx) {
             const int pieces = ctx->k + 1;
             for (; pos < idx.size(); ++pos) {
                 const PatternInfo &pi = ctx->pats[idx[pos]];
-                static const size_t max_keys = getenv("APM_MAX_KEYS") ? (size_t)atol(getenv("APM_MAX_KEYS")) : 4096; // measurement knob
+#ifdef APM_MEASURE
+                static const size_t max_keys = getenv("APM_MAX_KEYS") ? std::min<size_t>(32767, std::max<long>(1, atol(getenv("APM_MAX_KEYS")))) : 4096;
+#else
+                constexpr size_t max_keys = 4096; // (15-bit key ids: never above 32767)
+#endif
                 if (!L.descs.empty() && (L.bytes.size() + (size_t)pi.m > 16384 ||
                                          L.keys.size() + (size_t)pieces * stride > max_keys || L.descs.size() >= 1024 ||
                                          L.piece_off.size() + (size_t)pieces > 60000))
@@ -664,6 +690,7 @@ int build_plan(apm_ctx *ctx) {
         if ((rc = upload_vec(ctx, &ds.d_tail_descs, ctx->tails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_stail_descs, ctx->stails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_long_descs, ctx->longs.descs))) return rc;
+        if ((rc = upload_vec(ctx, &ds.d_trivial, ctx->trivial))) return rc;
         HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
         if (ctx->sieve.on && (rc = upload_vec(ctx, &ds.d_sieve_bmp, ctx->sieve.bitmap))) return rc;
         ds.tiled.resize(ctx->tiled.size());
@@ -702,10 +729,11 @@ int launch_generic_group(apm_ctx *ctx, DeviceState &ds, const GenericGroup &g, c
     if (mode == 1) span = std::min<int64_t>(span, g.m_max); // at most m-1 tail windows per pattern
     const size_t col = (size_t)g.m_max + 1;
     const size_t budget = (size_t)1 << 30;
+    const size_t per_launch = std::min<size_t>(g.descs.size(), 65535); // grid.y limit: more patterns = more launches
     int64_t nbx = (span + APM_BLOCK - 1) / APM_BLOCK;
-    const int64_t cap = std::max<int64_t>(1, (int64_t)(budget / (col * 2 * APM_BLOCK * g.descs.size())));
+    const int64_t cap = std::max<int64_t>(1, (int64_t)(budget / (col * 2 * APM_BLOCK * per_launch)));
     nbx = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nbx, cap), 4096));
-    const size_t need = col * 2 * APM_BLOCK * (size_t)nbx * g.descs.size();
+    const size_t need = col * 2 * APM_BLOCK * (size_t)nbx * per_launch;
     int rc = ensure_scratch(ctx, ds, need);
     if (rc) return rc;
     ApmGenericArgs a{};
@@ -722,8 +750,11 @@ int launch_generic_group(apm_ctx *ctx, DeviceState &ds, const GenericGroup &g, c
     a.scratch = ds.d_scratch;
     a.counts = d_counts;
     a.pos = sink;
-    HIP_TRY(ctx, apm_launch_generic(a, (int)nbx, (int)g.descs.size(), ds.stream));
-    ds.launches++;
+    for (size_t first = 0; first < g.descs.size(); first += per_launch) { // (same scratch: launches of one stream run in order)
+        a.pats = d_descs + first;
+        HIP_TRY(ctx, apm_launch_generic(a, (int)nbx, (int)std::min(per_launch, g.descs.size() - first), ds.stream));
+        { const int nrc = note_launch(ctx, ds, "generic"); if (nrc) return nrc; }
+    }
     return APM_OK;
 }
 
@@ -800,7 +831,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             sv.cand_n = ds.d_cand;
             sv.cand_cap = ds.cand_cap;
             HIP_TRY(ctx, apm_launch_sieve(sv, ds.n_cu, ds.stream));
-            ds.launches++;
+            { const int nrc = note_launch(ctx, ds, "sieve"); if (nrc) return nrc; }
             sieve_run = true;
         }
     }
@@ -838,10 +869,12 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.lg_nb = L.lg_nb;
             f.n_ovf = (int)(L.ovf.size() / 2);
             f.qcap = L.qcap;
-            if (L.stride == 1) { // measurement aid: APM_QCAP_S1 overrides the per-tile candidate queue of the per-position classes
+#ifdef APM_MEASURE
+            if (L.stride == 1) { // APM_QCAP_S1 overrides the per-tile candidate queue of the per-position classes
                 static const int q_env = getenv("APM_QCAP_S1") ? atoi(getenv("APM_QCAP_S1")) : 0;
                 if (q_env >= 64 && q_env <= 8192) f.qcap = q_env;
             }
+#endif
             f.key_len = L.key_len;
             f.stride = L.stride;
             f.counts = d_counts;
@@ -879,12 +912,12 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                     f.cand_cap = ds.cand_cap;
                     f.cand_mode = 1;
                     HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
-                    ds.launches++;
+                    { const int nrc = note_launch(ctx, ds, "stream(verify-only)"); if (nrc) return nrc; }
                     f.n_tail = 0; // (the tail workgroups ran with the launch above)
                     f.cand_mode = 2;
                 }
                 HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
-                ds.launches++;
+                { const int nrc = note_launch(ctx, ds, (f.cand_mode == 2 ? "stream(fallback)" : "stream")); if (nrc) return nrc; }
                 continue;
             }
             if (!ctx->tiled[t].blocks_per_cu[f.use_dma])
@@ -896,11 +929,14 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 tails_pending = false;
             }
             {
-                static const int bpc_env = getenv("APM_BPC_CAP") ? atoi(getenv("APM_BPC_CAP")) : 0; // measurement aid
-                const int bpc = bpc_env > 0 ? std::min(bpc_env, L.blocks_per_cu[f.use_dma]) : L.blocks_per_cu[f.use_dma];
+                int bpc = L.blocks_per_cu[f.use_dma];
+#ifdef APM_MEASURE
+                static const int bpc_env = getenv("APM_BPC_CAP") ? atoi(getenv("APM_BPC_CAP")) : 0;
+                if (bpc_env > 0) bpc = std::min(bpc_env, bpc);
+#endif
                 HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * bpc, ds.stream));
             }
-            ds.launches++;
+            { const int nrc = note_launch(ctx, ds, "tile"); if (nrc) return nrc; }
             continue;
         }
         ApmScanArgs a{};
@@ -924,7 +960,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         a.pos = sink;
         if (L.kind == APM_KERNEL_BITPAR) HIP_TRY(ctx, apm_launch_bitpar(a, ds.stream));
         else HIP_TRY(ctx, apm_launch_wavefront(a, ds.stream));
-        ds.launches++;
+        { const int nrc = note_launch(ctx, ds, (L.kind == APM_KERNEL_BITPAR ? "bitpar" : "wavefront")); if (nrc) return nrc; }
     }
     int rc = launch_generic_group(ctx, ds, ctx->longs, ds.d_long_descs, 2, d_text, avail, jb, je, nrel, d_counts, sink);
     if (rc) return rc;
@@ -935,11 +971,13 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     }
     if (tails_pending) {
         HIP_TRY(ctx, apm_launch_tail(ta, (int)ctx->stails.descs.size(), ds.stream));
-        ds.launches++;
+        { const int nrc = note_launch(ctx, ds, "tail"); if (nrc) return nrc; }
     }
-    for (int i : ctx->trivial)
-        hipLaunchKernelGGL(apm_add_const_kernel, dim3(1), dim3(64), 0, ds.stream, d_counts, i,
-                           (unsigned long long)(oe - ob));
+    if (!ctx->trivial.empty()) {
+        const int nt = (int)ctx->trivial.size();
+        hipLaunchKernelGGL(apm_add_const_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ds.stream, d_counts,
+                           ds.d_trivial, nt, (unsigned long long)(oe - ob));
+    }
     HIP_TRY(ctx, hipGetLastError());
     return APM_OK;
 }
@@ -974,6 +1012,7 @@ void begin_call(apm_ctx *ctx) {
     for (auto &ds : ctx->devs) {
         ds.text_bytes = 0;
         ds.launches = 0;
+        ds.n_stamps = 0;
         ds.events_recorded = false;
     }
 }
@@ -1229,6 +1268,7 @@ void apm_destroy(apm_ctx *ctx) {
         if (ds.d_text) hipFree(ds.d_text);
         if (ds.d_cand) hipFree(ds.d_cand);
         for (hipEvent_t e : ds.ev_stage) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : ds.ev_launch) if (e) hipEventDestroy(e);
         for (hipEvent_t e : {ds.ev_start, ds.ev_kstart, ds.ev_mstart, ds.ev_mstop, ds.ev_stop}) if (e) hipEventDestroy(e);
         if (ds.own_stream) hipStreamDestroy(ds.own_stream);
     }
@@ -1523,6 +1563,24 @@ int apm_get_timing(const apm_ctx *cctx, apm_timing *out) {
     if (rc) return rc;
     *out = ctx->timing;
     return APM_OK;
+}
+
+int apm_get_launch_times(const apm_ctx *cctx, int max, double *ms, const char **labels) {
+    apm_ctx *ctx = const_cast<apm_ctx *>(cctx);
+    if (!ctx || max < 0 || (max > 0 && !ms)) return APM_ERR_INVALID;
+    if (ctx->devs.empty()) return 0;
+    DeviceState &ds = ctx->devs[0];
+    if (!ds.events_recorded || ds.n_stamps == 0) return 0;
+    HIP_TRY(ctx, hipSetDevice(ds.dev));
+    HIP_TRY(ctx, hipEventSynchronize(ds.ev_launch[ds.n_stamps - 1]));
+    const int n = std::min(max, ds.n_stamps);
+    for (int i = 0; i < n; ++i) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, i ? ds.ev_launch[i - 1] : ds.ev_mstart, ds.ev_launch[i]) != hipSuccess) t = 0;
+        ms[i] = t;
+        if (labels) labels[i] = ds.launch_label[i];
+    }
+    return n;
 }
 
 int apm_device_alloc(apm_ctx *ctx, void **d_ptr, uint64_t bytes) {

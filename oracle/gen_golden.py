@@ -170,6 +170,26 @@ def main():
             pats.append("".join(p))
         add_text("dna20k_k%d" % k, text, k, pats)
 
+    # long, loose patterns (128 < m <= 256 with k > 7 or pieces shorter than 4 bytes: AUTO's WAVEFRONT route)
+    add_file("chrY_loose_long_k60", "small_chrY.fa", 60, [chrY_flat[300:300 + m] for m in (150, 200, 256)])
+    add_file("chrY_loose_long_k8", "small_chrY.fa", 8, [chrY_flat[77:77 + m] for m in (129, 200, 256)])
+    pats = []
+    for m in (129, 200, 256):
+        o = rnd.randrange(0, len(text) - m)
+        p = list(text[o:o + m])
+        for _e in range(9):
+            r, pos = rnd.random(), rnd.randrange(len(p))
+            if r < 0.5:
+                p[pos] = rnd.choice("ACGT")
+            elif r < 0.75:
+                del p[pos]
+                p.append(rnd.choice("ACGT"))
+            else:
+                p.insert(pos, rnd.choice("ACGT"))
+                p.pop()
+        pats.append("".join(p))
+    add_text("dna20k_loose_long_k9", text, 9, pats)
+
     tmpdir = tempfile.mkdtemp(prefix="apm_golden_")
 
     def solve(case):

@@ -26,6 +26,44 @@ def test_library_exports_every_declared_symbol():
     assert sorted(apm.ABI_SYMBOLS) == declared
 
 
+REFSHIM_SYMBOLS = ["getDeviceCount", "setDevice", "invoke_kernel", "write_kernel_result", "initializeGPU", "getGPUResult"]
+
+
+def test_library_exports_the_references_own_gpu_entry_points():
+    """include/apm_refshim.h: the six extern "C" symbols the reference's host files call
+    (src/main.c:18-19, src/patterns_over_ranks.c:33-36, src/database_over_ranks.c:18-22) -> link unmodified."""
+    lib = ctypes.CDLL(H.pkg().LIB_PATH)
+    hdr = open(os.path.join(H.ROOT, "include", "apm_refshim.h")).read()
+    for name in REFSHIM_SYMBOLS:
+        assert hasattr(lib, name), name
+        assert re.search(r"\b%s\s*\(" % name, hdr), name
+
+
+def test_product_library_has_no_measurement_switches():
+    """Stage-skipping and sizing knobs exist only under -DAPM_MEASURE (make measure -> libapm_hip_measure.so):
+    the shipped library must not even contain their names, so no environment variable can change its results."""
+    blob = open(H.pkg().LIB_PATH, "rb").read()
+    for name in (b"APM_FILTER_ABLATE", b"APM_MEASURE_SKIP", b"APM_MAX_KEYS", b"APM_BPC_CAP", b"APM_QCAP_S1"):
+        assert name not in blob, name
+    for sub in ("csrc/apm_kernels.hip", "csrc/apm_runtime.hip", "csrc/apm_sieve.hip"):
+        p = os.path.join(H.PKG_DIR, sub)
+        if not os.path.exists(p):
+            continue
+        depth, measure_depth = 0, None
+        for line in open(p):
+            t = line.strip()
+            if t.startswith("#if"):
+                depth += 1
+                if "APM_MEASURE" in t and measure_depth is None:
+                    measure_depth = depth
+            elif t.startswith("#endif"):
+                if measure_depth == depth:
+                    measure_depth = None
+                depth -= 1
+            elif measure_depth is None:
+                assert "getenv(\"APM_MEASURE" not in line and "skip_mask" not in line, (sub, line)
+
+
 def test_abi_version():
     assert H.pkg().load_library().apm_abi_version() == 1
 

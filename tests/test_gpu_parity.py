@@ -327,6 +327,103 @@ def test_baseline_sets_64mib_subset_vs_oracle(ctx, apm, cfg, idx):
             assert got[i] >= 1
 
 
+def _counts_from(raw, P):
+    return [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(P)]
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4", "cfg5"])
+def test_full_size_counts_pinned_by_full_dp_kernel(ctx, apm, cfg):
+    """BASELINE cfg3 (1 GiB) and the per-GPU shards of cfg4 / cfg5 (2^33 / 8 = 1 GiB) at FULL size: the counts of
+    AUTO (the exact-shortcut path: sieve / verify / tile kernels) must equal, pattern by pattern, those of the forced
+    BITPAR kernel, which evaluates every DP cell of every window (no filter, no candidate list), on the same
+    device-generated text; planted occurrences must be found; and a 4 MiB window in the middle of the text is
+    checked against the CPU oracle through apm_count_shard_device."""
+    import torch
+    wl = H.workloads()
+    c = wl.CONFIGS[cfg]
+    n, k, seed = 1 << 30, c["k"], wl.seed_of(c["cid"])
+    pats, planted = wl.make_patterns(n, c["lens"], k, seed)
+    P = len(pats)
+    m_max = max(len(p) for p in pats)
+    text = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+    cnt = torch.zeros(P, dtype=torch.int64, device="cuda:0")
+    with apm.ApmContext(device=0) as c2:
+        c2.set_patterns(pats, k)
+        c2.synth_fill_device(text.data_ptr(), 0, n, seed)
+        c2.synchronize()
+        got = {}
+        for variant in ("auto", "bitpar"):
+            c2.set_kernel(variant)
+            cnt.zero_()
+            torch.cuda.synchronize()
+            c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())
+            c2.synchronize()
+            got[variant] = cnt.cpu().tolist()
+        assert got["auto"] == got["bitpar"], cfg
+        for cc, (o, d) in zip(got["auto"], planted):
+            assert cc >= (1 if d <= k else 0)
+        # two mid-text windows against the oracle (banded form, pinned to the reference by the goldens): one at a
+        # 16-byte aligned device address (the sieve / stream kernels), one unaligned (register-staged tile kernel)
+        idx = list(range(P)) if P <= 32 else list(range(0, P, 8))
+        c2.set_kernel("auto")
+        for w0, wl_len in ((n // 2 - (1 << 21), 1 << 22), (n // 4 + 5, 1 << 21)):
+            host = apm.synth_fill_host(w0, wl_len + m_max - 1, seed)
+            want = H.oracle_counts(host, [pats[i] for i in idx], k, banded=True, j_end=wl_len)
+            cnt.zero_()
+            torch.cuda.synchronize()
+            c2.count_shard_device(text.data_ptr() + w0, w0, wl_len + m_max - 1, n, w0, w0 + wl_len, cnt.data_ptr())
+            c2.synchronize()
+            sub = cnt.cpu().tolist()
+            assert [sub[i] for i in idx] == want, (cfg, w0)
+    del text
+
+
+def test_auto_routes_long_loose_patterns_to_wavefront(ctx, apm):
+    """128 < m <= 256 where BANDED does not apply (k > 7 or pieces shorter than 4 bytes): the LDS/DPP wavefront
+    kernel, not the global-memory GENERIC one; m > 256 stays GENERIC; counts = the reference's (golden)."""
+    for name in ("chrY_loose_long_k60", "chrY_loose_long_k8", "dna20k_loose_long_k9"):
+        c = next(c for c in CASES if c["name"] == name)
+        ctx.set_kernel("auto")
+        ctx.set_patterns(c["patterns"], c["k"])
+        for i, p in enumerate(c["patterns"]):
+            assert ctx.pattern_kernel(i) == (2 if 128 < len(p) <= 256 else 3), (name, len(p))
+        assert ctx.count_buffer(H.case_text(c)) == c["counts"]
+    ctx.set_patterns([b"A" * 300], 100)
+    assert ctx.pattern_kernel(0) == 1
+
+
+def test_reference_gpu_entry_points_link_level(tmp_path):
+    """include/apm_refshim.h: a C program calls getDeviceCount/setDevice, invoke_kernel/write_kernel_result and
+    initializeGPU/getGPUResult exactly as the reference's host files do, linked against libapm_hip.so only."""
+    exe = str(tmp_path / "refshim_test")
+    subprocess.run(["gcc", "-O1", "-Wall", "-I", os.path.join(H.ROOT, "include"), os.path.join(H.ROOT, "tests", "refshim_test.c"),
+                    "-o", exe, "-L", H.PKG_DIR, "-lapm_hip", "-Wl,-rpath," + H.PKG_DIR, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    for name in ("x100_k2", "cfg1_basic_test", "chrY_k5"):
+        c = next(c for c in CASES if c["name"] == name)
+        text, pats, k = H.case_text(c), c["patterns"], c["k"]
+        n, P = len(text), len(pats)
+        r = subprocess.run([exe, str(k), c["path"]] + [p.decode() for p in pats], capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        lines = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in r.stdout.decode().splitlines() if l.strip()}
+        assert lines["devices"] == [1]
+        assert lines["invoke"] == c["counts"]                     # whole text = src/sequential.c's count
+        want34 = []
+        for p in pats:                                            # the GPU's share in patterns_over_ranks.c:316-326
+            part = min(n, 3 * n // 4 + len(p) - 1)
+            want34 += H.oracle_counts(text[:part], [p], k)
+        assert lines["invoke34"] == want34
+        last = P - 1 if P > 1 else P
+        for rank, (start, end) in enumerate([(0, n // 2), (n // 2, n)]):
+            want = []
+            for i, p in enumerate(pats):                          # searchPattern's per-rank arithmetic
+                if i >= last:
+                    want.append(0)
+                    continue
+                e = min(n, end + (len(p) - 1 if rank == 0 else 0))
+                want += H.oracle_counts(text[:e], [p], k, j_begin=start)
+            assert lines["db%d" % rank] == want, (name, rank)
+
+
 # ---------------------------------------------------------------- the C host (reference CLI contract)
 CLI = os.path.join(H.PKG_DIR, "host", "apm_parallel")
 
@@ -469,6 +566,34 @@ def test_rccl_allreduce_path_single_device(apm):
     r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert r.stdout.decode().strip().splitlines()[-1] == str(c["counts"])
+
+
+def test_bench_two_ranks_equal_one_rank():
+    """bench.py's N > 1 path (owner-computes shards + halo + all-reduce of the partial counts), rehearsed with two
+    ranks sharing this one GPU over gloo (RCCL refuses two ranks on one device): the summed counts must equal the
+    one-rank counts of the same text.  The ranks are started by torch.distributed.run from a fresh interpreter."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    per_gpu = 48 << 20
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants", "--no-per-config"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([os.sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "1", "--bytes-per-gpu", str(2 * per_gpu)] + common,
+                         capture_output=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    two = subprocess.run([os.sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(H.ROOT, "bench.py"),
+                          "--gpus", "2", "--dist-backend", "gloo", "--bytes-per-gpu", str(per_gpu)] + common,
+                         capture_output=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr.decode()[-2000:]
+    a = json.loads(one.stdout.decode().strip().splitlines()[-1])
+    b = json.loads(two.stdout.decode().strip().splitlines()[-1])
+    assert a["config"]["workload"].startswith("cfg3") and b["config"]["workload"].startswith("cfg3")
+    assert a["config"]["text_bytes_total"] == b["config"]["text_bytes_total"] == 2 * per_gpu
+    assert b["n_gpus"] == 2 and a["counts"] == b["counts"] and sum(a["counts"]) > 0
+    assert a["planted_occurrences_found"] and b["planted_occurrences_found"]
 
 
 # ---------------------------------------------------------------- filter corner cases (chains, overflow, big k)

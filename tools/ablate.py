@@ -1,8 +1,11 @@
-"""Measurement aid (GPU box): time the bench workload's scan kernel under ablations and a
-plain read of the same buffer.  Not part of the product or the test-suite."""
+"""Measurement aid (GPU box): time the bench workload's scan kernel with stages skipped and a
+plain read of the same buffer.  Uses the MEASUREMENT build of the library (make measure ->
+libapm_hip_measure.so, -DAPM_MEASURE): the product library has no such switches.
+Not part of the product or the test-suite."""
 import importlib, os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("APM_LIB_PATH", os.path.join(ROOT, "inf560-approximate-pattern-matching_amd", "libapm_hip_measure.so"))
 import torch
 apm = importlib.import_module("inf560-approximate-pattern-matching_amd")
 wl = importlib.import_module("inf560-approximate-pattern-matching_amd.workloads")
@@ -38,6 +41,6 @@ e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 10
 print("torch int64 sum over the text: %.3f ms  -> %.0f GB/s" % (t, n / t / 1e6))
 for ab in os.environ.get("ABLATIONS", "0,1,2,3").split(","):
-    os.environ["APM_FILTER_ABLATE"] = ab
+    os.environ["APM_MEASURE_SKIP"] = ab
     mn, av = run()
     print("ablate=%s  kernel min %.4f ms avg %.4f ms -> %.0f GB/s" % (ab, mn, av, n / mn / 1e6), "counts", counts.tolist()[:8])
