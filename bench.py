@@ -42,11 +42,12 @@ sys.path.insert(0, ROOT)
 PKG = "inf560-approximate-pattern-matching_amd"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# integer VALU ceiling: 256 CU x 4 SIMD x 64 lanes per wave instruction / cycles per instruction x 2.4 GHz.
-# tools/valu_probe.hip measures the cycles per wave64 instruction on the box (profiles/r02/valu_probe.txt);
-# DESIGN.md section 3 states the measured figure this constant follows.
-VALU_CYCLES_PER_WAVE_INSTR = 2.0
-VALU_PEAK_LANE_OPS = 256 * 4 * 64 / VALU_CYCLES_PER_WAVE_INSTR * 2.4e9
+# Integer VALU ceilings MEASURED on MI355X by tools/valu_probe.hip (profiles/r02/valu_probe.txt), chip-wide lane-ops/s
+# at >= 2 waves per SIMD: the simple class (v_add/sub/and/or/xor_b32, v_lshrrev_b32, v_mov_b32, v_bitop3_b32) issues a
+# wave64 instruction in 2 cycles per SIMD, everything else the scan kernels use (packed 16-bit v_pk_*, v_min*, DPP moves,
+# v_alignbit/bfe/lshl_or/and_or/perm/mad24/dot4, v_lshlrev) in 4: 7.0e13 vs 3.8e13 lane-ops/s.
+VALU_PEAK_LANE_OPS = 7.0e13          # simple class (the chip's integer VALU peak as measured)
+VALU_PACKED_CLASS_LANE_OPS = 3.8e13  # packed / DPP / 3-operand class: what the full-DP kernels are made of
 
 
 def parse():
@@ -339,6 +340,7 @@ def main():
                 variants["bitpar"] = {"cells_evaluated_per_s": cells / t_s, "kernel_ms": ms[-1], "sample": "full size",
                                       "counts_equal_headline": bool(ok),
                                       "valu_frac": bitpar_wave_instr(lens, positions) * 64 / t_s / VALU_PEAK_LANE_OPS,
+                                      "valu_frac_of_4cycle_class": bitpar_wave_instr(lens, positions) * 64 / t_s / VALU_PACKED_CLASS_LANE_OPS,
                                       "hbm_frac": shard_bytes / t_s / 1e9 / HBM_PEAK_GBS}
                 rec["counts_equal_bitpar"] = bool(ok)
             if max(lens) <= 256:
@@ -361,6 +363,7 @@ def main():
                                          "sample": "first %d window starts of the shard" % sl,
                                          "counts_equal_headline": bool(scratch.cpu().tolist() == ref_slice),
                                          "valu_frac": wavefront_wave_instr(lens, float(sl)) * 64 / t_s / VALU_PEAK_LANE_OPS,
+                                         "valu_frac_of_4cycle_class": wavefront_wave_instr(lens, float(sl)) * 64 / t_s / VALU_PACKED_CLASS_LANE_OPS,
                                          "hbm_frac": sl / t_s / 1e9 / HBM_PEAK_GBS}
             ctx.set_kernel(args.kernel)
             rec["variants"] = variants
@@ -431,8 +434,9 @@ def main():
         line["cpu_baseline_all_cores"] = cpu_all
     if per_config:
         line["per_config"] = per_config
-    line["valu_peak"] = {"lane_ops_per_s": VALU_PEAK_LANE_OPS, "cycles_per_wave64_instruction": VALU_CYCLES_PER_WAVE_INSTR,
-                         "source": "tools/valu_probe.hip (profiles/r02/valu_probe.txt)"}
+    line["valu_peak"] = {"lane_ops_per_s": VALU_PEAK_LANE_OPS, "lane_ops_per_s_4cycle_class": VALU_PACKED_CLASS_LANE_OPS,
+                         "source": "measured: tools/valu_probe.hip (profiles/r02/valu_probe.txt); valu_frac = modelled wave-instructions "
+                                   "(disassembly counts) x 64 lanes / kernel time / peak"}
 
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -1,34 +1,56 @@
-"""Copy the summaries of the last gpurun measurement into profiles/<round>/ and recompute
-profiles/traffic.json (measurement bookkeeping, run in the build container)."""
-import csv, json, os, shutil, sys
+"""Copy the summaries of a profiles/run_profiles.sh run (gpurun_out/prof_<tag>/<cfg>/) into profiles/<round>/ under a
+prefix, and recompute profiles/traffic.json for the bench's dominant kernel of each workload (measurement
+bookkeeping, run in the build container).
+    python tools/refresh_profiles.py <tag> <round> <prefix> [--traffic]
+HBM bytes per launch = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (MI355X_MICROARCH.md, HBM: gfx950 reports half of a
+wide coalesced read; separate --pmc passes)."""
+import json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
+tag, rnd, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
+G, P = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(P, exist_ok=True)
-pairs = [("bench_cfg2.json", "bench_cfg2_full.json"), ("prof_cfg2/trace_kernel_stats.csv", "bench_cfg2_kernel_stats.csv"),
-         ("pmc_fetch/pmc_counter_collection.csv", "bench_cfg2_pmc_FETCH_SIZE.csv"),
-         ("pmc_write/pmc_counter_collection.csv", "bench_cfg2_pmc_WRITE_SIZE.csv"),
-         ("bench_cfg3.json", "bench_cfg3_1GiB.json"), ("bench_cfg4.json", "bench_cfg4_pergpu_1GiB.json"),
-         ("bench_cfg5.json", "bench_cfg5_pergpu_1GiB.json"),
-         ("trace_cfg3/t_kernel_stats.csv", "tool_cfg3_1GiB_kernel_stats.csv"),
-         ("trace_cfg4/t_kernel_stats.csv", "tool_cfg4_1GiB_kernel_stats.csv"),
-         ("trace_cfg5/t_kernel_stats.csv", "tool_cfg5_1GiB_kernel_stats.csv")]
-for src, dst in pairs:
-    if os.path.exists(os.path.join(G, src)):
-        shutil.copyfile(os.path.join(G, src), os.path.join(P, dst))
-        print("copied", src, "->", dst)
 
-def mean_counter(path, counter, kernel_prefix):
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-         if r["Counter_Name"] == counter and kernel_prefix in r["Kernel_Name"]]
-    return sum(v) / len(v) if v else None
 
-kern = "apm_stream_kernel<0, 16, 16>"
-f = mean_counter(os.path.join(P, "bench_cfg2_pmc_FETCH_SIZE.csv"), "FETCH_SIZE", kern)
-w = mean_counter(os.path.join(P, "bench_cfg2_pmc_WRITE_SIZE.csv"), "WRITE_SIZE", kern)
-tpath = os.path.join(ROOT, "profiles", "traffic.json")
-t = json.load(open(tpath))
-t["cfg2:banded"] = {"fetch_size_kb": f, "write_size_kb": w, "traffic_bytes": int(round(2 * f * 1024 + w * 1024)),
-                    "round": rnd, "kernel": "apm_stream_kernel<0,16,16>"}
-json.dump(t, open(tpath, "w"), indent=1)
-print(t["cfg2:banded"])
+def parse_pmc(path):
+    """{kernel name: {counter: mean}}"""
+    out, cur = {}, None
+    for line in open(path):
+        if not line.startswith("   "):
+            cur = line.split(" | ")[0].strip()
+            out[cur] = {}
+        else:
+            m = re.match(r"\s+(\S+)\s+n=(\d+) mean=(\S+)", line)
+            out[cur][m.group(1)] = (float(m.group(3)), int(m.group(2)))
+    return out
+
+
+traffic_path = os.path.join(ROOT, "profiles", "traffic.json")
+traffic = json.load(open(traffic_path))
+for cfg in sorted(os.listdir(G)):
+    d = os.path.join(G, cfg)
+    for fn in ("kernel_stats.csv", "pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt", "pmc_SQ.txt", "bench.json"):
+        if os.path.exists(os.path.join(d, fn)):
+            shutil.copyfile(os.path.join(d, fn), os.path.join(P, "%s_%s_%s" % (prefix, cfg, fn)))
+    if "--traffic" not in sys.argv:
+        continue
+    bench = json.loads(open(os.path.join(d, "bench.json")).read().strip().splitlines()[-1])
+    f, w = parse_pmc(os.path.join(d, "pmc_FETCH_SIZE.txt")), parse_pmc(os.path.join(d, "pmc_WRITE_SIZE.txt"))
+    per_kernel = {}
+    for name in f:
+        if "apm_" not in name or "synth" in name:
+            continue
+        fs, n = f[name]["FETCH_SIZE"]
+        ws = w.get(name, {}).get("WRITE_SIZE", (0.0, n))[0]
+        per_kernel[name] = dict(launches_in_run=n, fetch_size_kb=fs, write_size_kb=ws, bytes_per_launch=int(round(2 * fs * 1024 + ws * 1024)))
+    # the step's dominant kernel = the one with the largest average duration in the kernel trace
+    import csv
+    rows = [r for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))) if "apm_" in r["Name"] and "synth" not in r["Name"]]
+    dom = max(rows, key=lambda r: float(r["AverageNs"]))["Name"]
+    dom_key = next((k for k in per_kernel if dom.startswith(k) or k.startswith(dom[:60])), None)
+    steps = bench["steps"] + bench["warmup"] + bench["steps"]          # timed + warm-up + the event-timed repeat
+    total = sum(v["bytes_per_launch"] * v["launches_in_run"] for v in per_kernel.values()) / steps
+    traffic["%s:%s" % (cfg, bench["config"]["kernel"])] = dict(
+        round=rnd, kernel=dom, traffic_bytes=per_kernel[dom_key]["bytes_per_launch"] if dom_key else None,
+        step_traffic_bytes=int(total), algorithmic_bytes=bench["roofline"]["algorithmic_bytes_per_launch"], per_kernel=per_kernel)
+    print(cfg, dom[:50], per_kernel.get(dom_key, {}).get("bytes_per_launch"), "step", int(total))
+json.dump(traffic, open(traffic_path, "w"), indent=1)

@@ -50,6 +50,22 @@ constexpr int ITER = 4096;
 #define OP_PERM(r) "v_perm_b32 " r ", " r ", %8, %9\n\t"
 #define OP_BCNT(r) "v_bcnt_u32_b32 " r ", " r ", %8\n\t"
 #define OP_ADDC(r) "v_add_co_u32 " r ", vcc, " r ", %8\n\t"
+#define OP_LSHR(r) "v_lshrrev_b32 " r ", 3, " r "\n\t"
+#define OP_LSHL(r) "v_lshlrev_b32 " r ", 1, " r "\n\t"
+#define OP_LSHRV(r) "v_lshrrev_b32 " r ", %8, " r "\n\t"
+#define OP_OR(r) "v_or_b32 " r ", " r ", %8\n\t"
+#define OP_XOR(r) "v_xor_b32 " r ", " r ", %8\n\t"
+#define OP_SUB(r) "v_sub_u32 " r ", " r ", %8\n\t"
+#define OP_MINU(r) "v_min_u32 " r ", " r ", %8\n\t"
+#define OP_MOV(r) "v_mov_b32 " r ", %8\n\t"
+#define OP_CNDMASK(r) "v_cndmask_b32 " r ", " r ", %8, vcc\n\t"
+#define OP_BFI(r) "v_bfi_b32 " r ", %8, " r ", %9\n\t"
+#define OP_OR3(r) "v_or3_b32 " r ", " r ", %8, %9\n\t"
+#define OP_ADD3(r) "v_add3_u32 " r ", " r ", %8, %9\n\t"
+#define OP_CMPSEL(r) "v_cmp_eq_u32 vcc, " r ", %8\n\tv_cndmask_b32 " r ", " r ", %9, vcc\n\t"
+#define OP_PKLSHR(r) "v_pk_lshrrev_b16 " r ", 1, " r "\n\t"
+#define OP_ALIGNBYTE(r) "v_alignbyte_b32 " r ", %8, " r ", 1\n\t"
+#define OP_MBCNT(r) "v_mbcnt_lo_u32_b32 " r ", %8, " r "\n\t"
 
 PROBE_KERNEL(k_add, R8(OP_ADD))
 PROBE_KERNEL(k_pkadd, R8(OP_PKADD))
@@ -70,6 +86,47 @@ PROBE_KERNEL(k_lshladd, R8(OP_LSHLADD))
 PROBE_KERNEL(k_perm, R8(OP_PERM))
 PROBE_KERNEL(k_bcnt, R8(OP_BCNT))
 PROBE_KERNEL(k_addc, R8(OP_ADDC))
+PROBE_KERNEL(k_lshr, R8(OP_LSHR))
+PROBE_KERNEL(k_lshl, R8(OP_LSHL))
+PROBE_KERNEL(k_lshrv, R8(OP_LSHRV))
+PROBE_KERNEL(k_or, R8(OP_OR))
+PROBE_KERNEL(k_xor, R8(OP_XOR))
+PROBE_KERNEL(k_sub, R8(OP_SUB))
+PROBE_KERNEL(k_minu, R8(OP_MINU))
+PROBE_KERNEL(k_mov, R8(OP_MOV))
+PROBE_KERNEL(k_cndmask, R8(OP_CNDMASK))
+PROBE_KERNEL(k_bfi, R8(OP_BFI))
+PROBE_KERNEL(k_or3, R8(OP_OR3))
+PROBE_KERNEL(k_add3, R8(OP_ADD3))
+PROBE_KERNEL(k_cmpsel, R8(OP_CMPSEL))
+PROBE_KERNEL(k_pklshr, R8(OP_PKLSHR))
+PROBE_KERNEL(k_alignbyte, R8(OP_ALIGNBYTE))
+PROBE_KERNEL(k_mbcnt, R8(OP_MBCNT))
+
+// random LDS reads out of a 32 KiB table (the presence-bitmap access pattern): 16 reads in flight, then a wait
+template <int BYTES>
+__global__ __launch_bounds__(256) void k_lds(unsigned long long *cycles, unsigned *sink, unsigned seed) {
+    __shared__ unsigned tab[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) tab[i] = i * 2654435761u + seed;
+    __syncthreads();
+    unsigned x = (seed + threadIdx.x) * 2246822519u, acc = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < ITER / 4; ++i) {
+        unsigned v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            x = x * 1664525u + 1013904223u;
+            const unsigned a = (x >> 9) & 32767u;
+            if constexpr (BYTES == 1) v[j] = reinterpret_cast<const unsigned char *>(tab)[a];
+            else v[j] = tab[a >> 2];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc ^= v[j];
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * 256 + threadIdx.x) >> 6] = t1 - t0;
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 
 typedef void (*kern_t)(unsigned long long *, unsigned *, unsigned);
 struct Probe { const char *name; kern_t fn; };
@@ -86,7 +143,12 @@ int main() {
                             {"v_min3_u32", k_min3}, {"v_bfe_u32", k_bfe}, {"v_alignbit_b32", k_alignbit}, {"v_lshl_or_b32", k_lshlor},
                             {"v_and_or_b32", k_andor}, {"v_bitop3_b32", k_bitop3}, {"v_mov_dpp shr1", k_dpp}, {"v_dot4_u32_u8", k_dot4},
                             {"v_mul_u32_u24", k_mulu24}, {"v_mad_u32_u24", k_mad24}, {"v_mul_lo_u32", k_mullo}, {"v_lshl_add_u32", k_lshladd},
-                            {"v_perm_b32", k_perm}, {"v_bcnt_u32_b32", k_bcnt}, {"v_add_co_u32", k_addc}};
+                            {"v_perm_b32", k_perm}, {"v_bcnt_u32_b32", k_bcnt}, {"v_add_co_u32", k_addc},
+                            {"v_lshrrev imm", k_lshr}, {"v_lshlrev imm", k_lshl}, {"v_lshrrev vgpr", k_lshrv}, {"v_or_b32", k_or},
+                            {"v_xor_b32", k_xor}, {"v_sub_u32", k_sub}, {"v_min_u32", k_minu}, {"v_mov_b32", k_mov},
+                            {"v_cndmask_b32", k_cndmask}, {"v_bfi_b32", k_bfi}, {"v_or3_b32", k_or3}, {"v_add3_u32", k_add3},
+                            {"v_cmp+cndmask/2", k_cmpsel}, {"v_pk_lshrrev_b16", k_pklshr}, {"v_alignbyte_b32", k_alignbyte},
+                            {"v_mbcnt_lo", k_mbcnt}};
     unsigned long long *d_cyc;
     unsigned *d_sink;
     const int max_blocks = ncu * 8;
@@ -113,6 +175,28 @@ int main() {
             const double n_instr = (double)ITER * 32.0;
             printf("  %-14s %10d %22.3f %26.3f %20.4e\n", p.name, w, med / n_instr, med / n_instr / w,
                    (double)nblk * 4 * 64 * n_instr / (ms * 1e-3));
+        }
+    }
+    printf("# random LDS reads from a 32 KiB table (per read: 1 LCG mul+add, 1 bfe/shift, the read): cycles per read per wave, reads/s chip-wide\n");
+    for (int bytes : {1, 4}) {
+        for (int w : {1, 2, 4}) {
+            const int nblk = ncu * w;
+            auto fn = bytes == 1 ? k_lds<1> : k_lds<4>;
+            fn<<<nblk, 256>>>(d_cyc, d_sink, 1u);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0));
+            fn<<<nblk, 256>>>(d_cyc, d_sink, 2u);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            std::vector<unsigned long long> h((size_t)nblk * 4);
+            CHECK(hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost));
+            std::sort(h.begin(), h.end());
+            const double n_reads = (double)(ITER / 4) * 16.0;
+            printf("  ds_read_%s random %2d waves/SIMD: %8.2f cycles per wave-read, %.3e wave-reads/s per CU, %.3e lane-reads/s chip\n",
+                   bytes == 1 ? "u8 " : "b32", w, (double)h[h.size() / 2] / n_reads, (double)w * 4 * n_reads / (ms * 1e-3),
+                   (double)nblk * 256 * n_reads / (ms * 1e-3));
         }
     }
     return 0;
