@@ -322,6 +322,9 @@ def main():
         }
         if exact_k0 is not None:
             rec["counts_equal_closed_form_k0"] = exact_k0
+        if ctx.stat("sieve_on"):
+            rec["sieve"] = {key: ctx.stat(key) for key in ("sieve_rate", "sieve_capacity", "sieve_candidates", "sieve_overflow",
+                                                            "verify_launches", "verify_image_bytes", "verify_blocks_per_cu")}
 
         # full-DP kernel variants, reported under their own label (cells really evaluated)
         if with_variants and world == 1:
@@ -426,7 +429,7 @@ def main():
         "event_ms_per_step": head["event_ms_per_step"],
         "roofline": head["roofline"],
     }
-    for key in ("counts_equal_bitpar", "counts_equal_closed_form_k0", "variants"):
+    for key in ("counts_equal_bitpar", "counts_equal_closed_form_k0", "sieve", "variants"):
         if key in head:
             line[key] = head[key]
     if cpu1 is not None:

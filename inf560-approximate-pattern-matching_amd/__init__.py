@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "apm_device_count", "apm_abi_version", "apm_create", "apm_create_on_device", "apm_destroy",
     "apm_last_error", "apm_set_stream", "apm_set_patterns", "apm_set_kernel", "apm_count_buffer",
     "apm_count_file", "apm_find_buffer", "apm_count_shard_device", "apm_shard_range", "apm_synth_fill_device",
-    "apm_synth_fill_host", "apm_count_synthetic", "apm_set_timing", "apm_get_timing", "apm_get_launch_times",
+    "apm_synth_fill_host", "apm_count_synthetic", "apm_set_timing", "apm_get_timing", "apm_get_launch_times", "apm_get_stat",
     "apm_pattern_kernel",
     "apm_device_alloc", "apm_device_free", "apm_device_upload", "apm_device_download",
     "apm_device_memset", "apm_synchronize",
@@ -89,6 +89,7 @@ def load_library():
         "apm_set_timing": (i32, [vp, i32]),
         "apm_get_timing": (i32, [vp, c.POINTER(ApmTiming)]),
         "apm_get_launch_times": (i32, [vp, i32, c.POINTER(c.c_double), c.POINTER(c.c_char_p)]),
+        "apm_get_stat": (i32, [vp, c.c_char_p, c.POINTER(c.c_double)]),
         "apm_pattern_kernel": (i32, [vp, i32]),
         "apm_device_alloc": (i32, [vp, c.POINTER(vp), u64]),
         "apm_device_free": (i32, [vp, vp]),
@@ -235,6 +236,11 @@ class ApmContext:
         if n < 0:
             self._check(n)
         return [((labels[i] or b"?").decode(), ms[i]) for i in range(n)]
+
+    def stat(self, name):
+        v = ctypes.c_double()
+        self._check(self._lib.apm_get_stat(self._ctx, name.encode(), ctypes.byref(v)))
+        return v.value
 
     def synchronize(self):
         self._check(self._lib.apm_synchronize(self._ctx))

@@ -1,0 +1,156 @@
+/*
+ * apm_device.h -- device helpers shared by the kernel translation units (apm_kernels.hip, apm_sieve.hip).
+ */
+#ifndef APM_DEVICE_H
+#define APM_DEVICE_H
+
+#include "apm_internal.h"
+#include "apm_core.h"
+
+__device__ __forceinline__ uint32_t apm_wave_count(bool pred) {
+    return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred));
+}
+
+__device__ __forceinline__ int apm_min3(int a, int b, int c) { return min(min(a, b), c); }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 apm_as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+
+// N dwords of bytes starting at (16-byte aligned LDS base) + off, any alignment of off:
+// N+1 aligned ds_read_b32 + N v_alignbyte -- no dependent byte loads
+template <int N>
+__device__ __forceinline__ void apm_lds_dwords(const uint8_t *base, int off, uint32_t (&out)[N]) {
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(base) + (off >> 2);
+    const uint32_t sh = (uint32_t)off & 3u;
+    uint32_t w[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; ++i) w[i] = a[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+}
+
+// Banded DP (|x-y| <= BAND) with early exit over a window of m text bytes vs pattern pb[poff..poff+m).
+// Columns 1..16 run out of registers (bytes fetched as dwords up front, statically indexed); most
+// candidates die there.  Needs m >= 16 for the register phase, otherwise byte loop only.
+template <int BAND, typename Text>
+__device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t *pb, int poff, int m, int k) {
+    const uint8_t *p = pb + poff;
+    if constexpr (BAND == 0) {
+        int mism = 0;
+        for (int x = 0; x < m; ++x) {
+            mism += (tx.byte(x) != (int)p[x]) ? 1 : 0;
+            if (mism > k) return false;
+        }
+        return true;
+    } else {
+        constexpr int NB = 2 * BAND + 1;
+        constexpr int INF = 1 << 20;
+        int e[NB]; // e[d+BAND] = cell(x, x+d)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) e[i] = (i >= BAND) ? (i - BAND) : INF; // cell(0, d) = d
+        int x0 = 1;
+        if (m >= 16 && tx.can16(m)) {
+            uint32_t T[4], P[5];
+            tx.load16(T);
+            apm_lds_dwords<5>(pb, poff, P); // pattern bytes 0..19 (>= 16 + BAND - 1)
+#pragma unroll
+            for (int x = 1; x <= 16; ++x) {
+                const int tc = (int)((T[(x - 1) >> 2] >> (8 * ((x - 1) & 3))) & 0xffu);
+                int up = INF, best = INF;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const int y = x + i - BAND; // static
+                    int nv;
+                    if (y < 1) {
+                        nv = (y == 0) ? x : INF;
+                    } else if (y > 16 && y > m) { // only reachable for 16 <= m < 16 + BAND
+                        nv = INF;
+                    } else {
+                        const int pc = (int)((P[(y - 1) >> 2] >> (8 * ((y - 1) & 3))) & 0xffu);
+                        const int diag = e[i] + ((pc != tc) ? 1 : 0);
+                        const int left = (i + 1 < NB) ? e[i + 1] + 1 : INF;
+                        nv = apm_min3(diag, left, up + 1);
+                    }
+                    e[i] = nv;
+                    up = nv;
+                    best = min(best, nv);
+                }
+                if ((x & 3) == 0 && best > k) return false;
+            }
+            x0 = 17;
+        }
+        for (int x = x0; x <= m; ++x) {
+            const int tc = tx.byte(x - 1);
+            int up = INF; // cell(x, y-1) of the previous diagonal at this x
+            int best = INF;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int y = x + i - BAND;
+                int nv;
+                if (y < 1) {
+                    nv = (y == 0) ? x : INF;
+                } else if (y > m) {
+                    nv = INF;
+                } else {
+                    const int diag = e[i] + (((int)p[y - 1] != tc) ? 1 : 0);
+                    const int left = (i + 1 < NB) ? e[i + 1] + 1 : INF;
+                    nv = apm_min3(diag, left, up + 1);
+                }
+                e[i] = nv;
+                up = nv;
+                best = min(best, nv);
+            }
+            if (best > k) return false;
+        }
+        return e[BAND] <= k;
+    }
+}
+
+__device__ __forceinline__ uint32_t apm_bswap(uint32_t v) { return __builtin_bswap32(v); }
+
+// match-position sink (apm_find_buffer): rare, unordered; the host sorts
+__device__ __forceinline__ void apm_push_pos(const ApmPosSink &ps, int64_t j_rel) {
+    const unsigned long long idx = atomicAdd(ps.count, 1ull);
+    if (idx < ps.cap) ps.out[idx] = ps.text_off + (unsigned long long)j_rel;
+}
+
+
+// body shared by apm_tail_kernel and by the extra workgroups of the BANDED launch;
+// needs >= 128 threads, uses lanes 0..127; s_eq = 256 uint4 of LDS
+__device__ __forceinline__ void apm_tail_body(const ApmTailArgs &a, int pat_slot, uint4 *s_eq, int tid) {
+    const ApmPatDesc d = a.pats[pat_slot];
+    const int m = (int)d.m;
+    const uint8_t *pat = a.bytes + d.byte_off;
+    uint32_t *eqw = reinterpret_cast<uint32_t *>(s_eq);
+    uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_eq + 256); // last <= 128 text bytes
+    for (int i = tid; i < 1024; i += 128) eqw[i] = 0u;
+    const int64_t first_trunc = max(a.jb, a.nrel - m + 1);
+    const int64_t t0 = a.nrel - 128 > 0 ? a.nrel - 128 : 0; // stage the end of the text once
+    if (tid < 128) s_txt[tid] = (t0 + tid < a.nrel) ? a.text[t0 + tid] : (uint8_t)0;
+    __syncthreads();
+    if (tid < m) atomicOr(&eqw[(int)pat[tid] * 4 + (tid >> 5)], 1u << (tid & 31));
+    __syncthreads();
+    if (tid < 128) {
+        const int64_t j = first_trunc + tid;
+        const bool valid = j < a.je;
+        const int size = valid ? (int)(a.nrel - j) : 0; // 1 .. m-1 (<= 127)
+        const int lo = valid ? (int)(j - t0) : 0;
+        uint32_t pv[4], mv[4];
+        bp_init<4>(pv, mv);
+        for (int x = 0; x < m - 1; ++x) {
+            if (x < size) {
+                const uint4 v = s_eq[s_txt[lo + x]];
+                const uint32_t eq[4] = {v.x, v.y, v.z, v.w};
+                bp_step<4>(pv, mv, eq);
+            }
+        }
+        const bool hit = valid && bp_distance<4>(pv, mv, size, size) <= a.k;
+        if (a.pos.out && hit) apm_push_pos(a.pos, j);
+        const uint32_t cnt = apm_wave_count(hit);
+        if ((tid & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
+    }
+}
+
+
+#endif /* APM_DEVICE_H */

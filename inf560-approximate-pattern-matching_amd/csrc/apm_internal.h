@@ -133,33 +133,12 @@ struct ApmFilterArgs {
     int n_main_blocks;     /* set by the launcher: persistent scan workgroups */
     int n_tail;            /* extra workgroups, one per tail pattern (0: tails launched separately) */
     ApmTailArgs tail;
-    /* candidate list of a preceding apm_sieve_kernel pass (stream kernel only):
-       cand_mode 0: none (the kernel streams the text itself);
-       cand_mode 1: verify-only -- no text streaming, the queued positions are verified (nothing is done
-                    if the list overflowed: *cand_n > cand_cap);
-       cand_mode 2: fallback -- the normal streaming scan, but only if the list overflowed */
-    const unsigned long long *cand;
+    /* cand_mode 2: this launch is the fallback of the sieve + verify pipeline (apm_sieve.hip) for its patterns:
+       the normal scan, but only if the pipeline's candidate list overflowed (*cand_n > cand_cap, read on the
+       device); cand_mode 0: unconditional scan */
     const unsigned long long *cand_n;
     unsigned long long cand_cap;
     int cand_mode;
-};
-
-/* one pass over the text for all sparse per-position classes of a pattern set: 2-bit byte codes against
-   ONE presence bitmap over 8-byte code words (shorter keys are entered with all their extensions); the
-   candidate positions go to a global list that the per-class verify launches consume */
-struct ApmSieveArgs {
-    const uint8_t *text;
-    int64_t avail_pad;
-    int64_t tile0;          /* first scanned relative position (multiple of 16) */
-    int64_t nchunks;        /* 1 KiB chunks */
-    const uint4 *bitmap;    /* 8 KiB: bit of code word x in byte x & 8191, bit x >> 13 */
-    int code_shift;
-#ifdef APM_MEASURE
-    int skip_mask;
-#endif
-    unsigned long long *cand;
-    unsigned long long *cand_n;
-    unsigned long long cand_cap;
 };
 
 #define APM_TAG_EMPTY 0x5bd1e995u
@@ -180,7 +159,6 @@ size_t apm_filter_lds_bytes(const ApmFilterArgs &a);
 int apm_filter_blocks_per_cu(int band, int key_len, int stride, int dma, size_t lds);
 hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t s);
 int apm_stream_blocks_per_cu(const ApmFilterArgs &a);
-hipError_t apm_launch_sieve(const ApmSieveArgs &a, int n_cu, hipStream_t s);
 hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s);

@@ -18,6 +18,7 @@
  */
 #include "apm_internal.h"
 #include "apm_core.h"
+#include "apm_device.h"
 
 // ---------------------------------------------------------------------------
 // helpers
@@ -33,17 +34,6 @@ __device__ __forceinline__ uint4 apm_load16_guarded(const uint8_t *text, int64_t
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-__device__ __forceinline__ uint32_t apm_wave_count(bool pred) {
-    return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred));
-}
-
-__device__ __forceinline__ int apm_min3(int a, int b, int c) { return min(min(a, b), c); }
-
-// match-position sink (apm_find_buffer): rare, unordered; the host sorts
-__device__ __forceinline__ void apm_push_pos(const ApmPosSink &ps, int64_t j_rel) {
-    const unsigned long long idx = atomicAdd(ps.count, 1ull);
-    if (idx < ps.cap) ps.out[idx] = ps.text_off + (unsigned long long)j_rel;
-}
 
 // lane l receives lane (l-1)'s value; lane 0 keeps `self` (DPP wave_shr:1, 1 VALU op)
 __device__ __forceinline__ int apm_shift_up1(int v) {
@@ -415,42 +405,6 @@ hipError_t apm_launch_synth(uint8_t *dst, uint64_t global_off, uint64_t len, uin
 // One 128-lane workgroup per pattern; each lane runs the 4-word bit-vector
 // column for `size` steps over an Eq table built in LDS.
 // ---------------------------------------------------------------------------
-// body shared by apm_tail_kernel and by the extra workgroups of the BANDED launch;
-// needs >= 128 threads, uses lanes 0..127; s_eq = 256 uint4 of LDS
-__device__ __forceinline__ void apm_tail_body(const ApmTailArgs &a, int pat_slot, uint4 *s_eq, int tid) {
-    const ApmPatDesc d = a.pats[pat_slot];
-    const int m = (int)d.m;
-    const uint8_t *pat = a.bytes + d.byte_off;
-    uint32_t *eqw = reinterpret_cast<uint32_t *>(s_eq);
-    uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_eq + 256); // last <= 128 text bytes
-    for (int i = tid; i < 1024; i += 128) eqw[i] = 0u;
-    const int64_t first_trunc = max(a.jb, a.nrel - m + 1);
-    const int64_t t0 = a.nrel - 128 > 0 ? a.nrel - 128 : 0; // stage the end of the text once
-    if (tid < 128) s_txt[tid] = (t0 + tid < a.nrel) ? a.text[t0 + tid] : (uint8_t)0;
-    __syncthreads();
-    if (tid < m) atomicOr(&eqw[(int)pat[tid] * 4 + (tid >> 5)], 1u << (tid & 31));
-    __syncthreads();
-    if (tid < 128) {
-        const int64_t j = first_trunc + tid;
-        const bool valid = j < a.je;
-        const int size = valid ? (int)(a.nrel - j) : 0; // 1 .. m-1 (<= 127)
-        const int lo = valid ? (int)(j - t0) : 0;
-        uint32_t pv[4], mv[4];
-        bp_init<4>(pv, mv);
-        for (int x = 0; x < m - 1; ++x) {
-            if (x < size) {
-                const uint4 v = s_eq[s_txt[lo + x]];
-                const uint32_t eq[4] = {v.x, v.y, v.z, v.w};
-                bp_step<4>(pv, mv, eq);
-            }
-        }
-        const bool hit = valid && bp_distance<4>(pv, mv, size, size) <= a.k;
-        if (a.pos.out && hit) apm_push_pos(a.pos, j);
-        const uint32_t cnt = apm_wave_count(hit);
-        if ((tid & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
-    }
-}
-
 __global__ __launch_bounds__(128) void apm_tail_kernel(ApmTailArgs a) {
     __shared__ uint4 s_eq[256 + 8];
     apm_tail_body(a, (int)blockIdx.x, s_eq, (int)threadIdx.x);
@@ -494,9 +448,6 @@ hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s) {
 // the same verification over every (sampled position, key) of the tile.
 // Per launch the text is read from HBM exactly once (+ halo per tile).
 // ---------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ u16x2 apm_as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
 __device__ __forceinline__ uint32_t apm_fp8(uint32_t lo, uint32_t hi) {
     return lo + (hi << 3); // v_lshl_add_u32; injective on ACGT 8-mers (no carries between bytes)
@@ -516,18 +467,6 @@ __device__ __forceinline__ uint32_t apm_table_hash(uint32_t f) {
     else return apm_slot_hash(f);
 }
 
-// N dwords of bytes starting at (16-byte aligned LDS base) + off, any alignment of off:
-// N+1 aligned ds_read_b32 + N v_alignbyte -- no dependent byte loads
-template <int N>
-__device__ __forceinline__ void apm_lds_dwords(const uint8_t *base, int off, uint32_t (&out)[N]) {
-    const uint32_t *a = reinterpret_cast<const uint32_t *>(base) + (off >> 2);
-    const uint32_t sh = (uint32_t)off & 3u;
-    uint32_t w[N + 1];
-#pragma unroll
-    for (int i = 0; i <= N; ++i) w[i] = a[i];
-#pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
-}
 
 // mask of the key bytes living in the second dword of an (up to) 8-byte key
 template <int KL>
@@ -577,82 +516,6 @@ struct ApmGlobalText {
     __device__ __forceinline__ int byte(int x) const { return (int)text[off + x]; }
 };
 
-// Banded DP (|x-y| <= BAND) with early exit over a window of m text bytes vs pattern pb[poff..poff+m).
-// Columns 1..16 run out of registers (bytes fetched as dwords up front, statically indexed); most
-// candidates die there.  Needs m >= 16 for the register phase, otherwise byte loop only.
-template <int BAND, typename Text>
-__device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t *pb, int poff, int m, int k) {
-    const uint8_t *p = pb + poff;
-    if constexpr (BAND == 0) {
-        int mism = 0;
-        for (int x = 0; x < m; ++x) {
-            mism += (tx.byte(x) != (int)p[x]) ? 1 : 0;
-            if (mism > k) return false;
-        }
-        return true;
-    } else {
-        constexpr int NB = 2 * BAND + 1;
-        constexpr int INF = 1 << 20;
-        int e[NB]; // e[d+BAND] = cell(x, x+d)
-#pragma unroll
-        for (int i = 0; i < NB; ++i) e[i] = (i >= BAND) ? (i - BAND) : INF; // cell(0, d) = d
-        int x0 = 1;
-        if (m >= 16 && tx.can16(m)) {
-            uint32_t T[4], P[5];
-            tx.load16(T);
-            apm_lds_dwords<5>(pb, poff, P); // pattern bytes 0..19 (>= 16 + BAND - 1)
-#pragma unroll
-            for (int x = 1; x <= 16; ++x) {
-                const int tc = (int)((T[(x - 1) >> 2] >> (8 * ((x - 1) & 3))) & 0xffu);
-                int up = INF, best = INF;
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int y = x + i - BAND; // static
-                    int nv;
-                    if (y < 1) {
-                        nv = (y == 0) ? x : INF;
-                    } else if (y > 16 && y > m) { // only reachable for 16 <= m < 16 + BAND
-                        nv = INF;
-                    } else {
-                        const int pc = (int)((P[(y - 1) >> 2] >> (8 * ((y - 1) & 3))) & 0xffu);
-                        const int diag = e[i] + ((pc != tc) ? 1 : 0);
-                        const int left = (i + 1 < NB) ? e[i + 1] + 1 : INF;
-                        nv = apm_min3(diag, left, up + 1);
-                    }
-                    e[i] = nv;
-                    up = nv;
-                    best = min(best, nv);
-                }
-                if ((x & 3) == 0 && best > k) return false;
-            }
-            x0 = 17;
-        }
-        for (int x = x0; x <= m; ++x) {
-            const int tc = tx.byte(x - 1);
-            int up = INF; // cell(x, y-1) of the previous diagonal at this x
-            int best = INF;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int y = x + i - BAND;
-                int nv;
-                if (y < 1) {
-                    nv = (y == 0) ? x : INF;
-                } else if (y > m) {
-                    nv = INF;
-                } else {
-                    const int diag = e[i] + (((int)p[y - 1] != tc) ? 1 : 0);
-                    const int left = (i + 1 < NB) ? e[i + 1] + 1 : INF;
-                    nv = apm_min3(diag, left, up + 1);
-                }
-                e[i] = nv;
-                up = nv;
-                best = min(best, nv);
-            }
-            if (best > k) return false;
-        }
-        return e[BAND] <= k;
-    }
-}
 
 // ---- hierarchical verification (per-position key classes) ---------------------------------
 // The k+1 pigeonhole pieces are paired (0,1), (2,3), ...  With <= k edits in the window some pair
@@ -665,7 +528,6 @@ __device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t 
 // mismatching byte i; the three ways to spend it are checked with shifted compares: substitution (P vs T),
 // pattern byte without text counterpart (P vs T<<8), one extra text byte (P vs T>>8).  Longer partners (only
 // when long patterns joined a per-position class) take the byte loops of apm_ext_fwd / apm_ext_bwd.
-__device__ __forceinline__ uint32_t apm_bswap(uint32_t v) { return __builtin_bswap32(v); }
 // (apm_ext1_core16 lives in apm_core.h: tests/host_core_test.cpp checks it against the byte loops on the host)
 // pattern pb[pp..pp+n) vs text read FORWARD from tb[tp]: <= 1 edit, all of the pattern consumed
 __device__ __forceinline__ bool apm_ext_fwd(const uint8_t *tb, int tp, const uint8_t *pb, int pp, int n) {
@@ -713,6 +575,8 @@ void apm_filter_kernel(ApmFilterArgs a) {
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
+    // fallback of the sieve + verify pipeline (apm_sieve.hip): nothing to do unless its candidate list overflowed
+    if (a.cand_mode == 2 && *a.cand_n <= a.cand_cap) return;
     // LDS: [tile 0 | tile 1 | (tile 2) | launch image (pattern bytes, hash table, key/pattern records) | queue | counts]
     // LDS-DMA: three tile buffers; the per-position classes keep a fourth so that the tile before the current
     // one stays intact and two tiles are verified in ONE pass (see the tile loop)
@@ -1287,12 +1151,9 @@ void apm_stream_kernel(ApmFilterArgs a) {
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
-    // candidate-list modes (see ApmFilterArgs): a uniform early exit before anything is staged
-    unsigned long long n_cand = 0;
-    if (a.cand_mode) {
-        n_cand = *a.cand_n;
-        if ((a.cand_mode == 1) == (n_cand > a.cand_cap)) return; // verify-only of an overflowed list / fallback not needed
-    }
+    // fallback of the sieve + verify pipeline (apm_sieve.hip): nothing to do unless its candidate list overflowed
+    // (a uniform early exit before anything is staged)
+    if (a.cand_mode == 2 && *a.cand_n <= a.cand_cap) return;
     constexpr int NSH = 2 * BAND + 1;
     constexpr bool PAIRS = (STRIDE == 1) && (BAND >= 1);
     constexpr int GRP = 4;                        // probes between two flush checks
@@ -1315,7 +1176,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
 
     const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
     const int64_t W = (int64_t)a.n_main_blocks * (APM_BLOCK / 64);
-    const int64_t nch = a.cand_mode == 1 ? 0 : a.ntiles; // 1 KiB chunks from relative position a.tile0 (multiple of 16)
+    const int64_t nch = a.ntiles; // 1 KiB chunks from relative position a.tile0 (multiple of 16)
     const uint8_t *text = a.text;
     const int64_t limit = a.avail_pad;
 
@@ -1617,138 +1478,13 @@ void apm_stream_kernel(ApmFilterArgs a) {
             }
         }
     }
-    // the last partial queue -- or, verify-only mode, the sieve's candidate list in batches of 64 per wave
-    // (same single verification site)
-    for (unsigned long long ci = (unsigned long long)((int64_t)blockIdx.x * (APM_BLOCK / 64) + wv) * 64u;;
-         ci += (unsigned long long)W * 64u) {
-        if (a.cand_mode == 1) {
-            if (ci >= n_cand) break;
-            const unsigned long long left = n_cand - ci;
-            qcount = left < 64u ? (uint32_t)left : 64u;
-            if ((uint32_t)lane < qcount) {
-                const unsigned long long pp = a.cand[ci + (unsigned long long)lane];
-                s_queue[lane] = make_uint2((uint32_t)pp, (uint32_t)(pp >> 32));
-            }
-        }
-        flush(qcount);
-        if (a.cand_mode != 1) break;
-    }
+    flush(qcount); // the last partial queue (same single verification site)
 
     __syncthreads();
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
         const uint32_t cnt = s_cnt[i];
         if (cnt) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)cnt);
     }
-}
-
-// ---------------------------------------------------------------------------
-// SIEVE: one wave-autonomous pass over the text for ALL sparse per-position classes of a pattern set.
-// Same chunking and loads as apm_stream_kernel (16 bytes per lane + the 8 that follow, four chunks in
-// flight), same 2-bit-code bitmap test per position -- against one 8 KiB bitmap over 8-byte code words
-// into which the host entered every participating key (a 6-byte key with its 16 extensions).  No
-// verification code lives here (~45 VGPRs, full occupancy): hit positions are appended to a global list,
-// one aggregated atomic per wave and round, and the per-class verify-only launches of apm_stream_kernel
-// take it from there.  An overflowing list (counter > capacity) turns those launches into no-ops and
-// their fallback twins into full scans, so the result never depends on the list fitting.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(APM_BLOCK, 5) void apm_sieve_kernel(ApmSieveArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < 512; i += APM_BLOCK) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
-    __syncthreads();
-    const apm_lds_u8 *bmp0 = (const apm_lds_u8 *)(uintptr_t)0; // the bitmap leads this kernel's LDS (no static LDS)
-    const int64_t W = (int64_t)gridDim.x * (APM_BLOCK / 64);
-    const int64_t nch = a.nchunks;
-
-    auto load_chunk = [&](int64_t cc, u32x4 &r, uint2 &e) __attribute__((always_inline)) {
-        const int64_t g = a.tile0 + cc * 1024;
-        const int64_t lim = cc < nch ? a.avail_pad - g : 0;
-        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1040 ? 1040u : (uint32_t)lim);
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
-        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
-        typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-        const u32x2v x = __builtin_amdgcn_raw_buffer_load_b64(rs, 16 * lane + 16, 0, 0);
-        e = make_uint2(x.x, x.y);
-    };
-    auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { // 4 bytes -> 8 code bits
-        const uint32_t cd = (w4 >> a.code_shift) & 0x03030303u;
-        const uint32_t u = cd | (cd >> 6);
-        return (u | (u >> 12)) & 0xffu;
-    };
-    auto hit_bits = [&](const u32x4 &v, const uint2 &e, int64_t cc) __attribute__((always_inline)) {
-        const uint32_t clo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
-        const uint32_t chi = pack4(e.x) | (pack4(e.y) << 8);
-        uint32_t hits = 0;
-#pragma unroll
-        for (int i = 15; i >= 0; --i) {
-            const uint32_t x = i ? __builtin_amdgcn_alignbit(chi, clo, 2u * (uint32_t)i) : clo;
-            const uint32_t byte = bmp0[x & 8191u];
-            hits = (hits << 1) | __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(x, 13, 3), 1);
-        }
-        return (cc < nch && !APM_SKIP(a, 1)) ? hits : 0u;
-    };
-    // hit positions are staged in a wave-private LDS queue (ballot + mbcnt, no atomics) and leave for the
-    // global list 192+ at a time: one global atomic per batch, not per hit
-    constexpr int SQ = 256; // queue entries per wave: spilled to the list once it holds >= SQ - 64
-    unsigned long long *s_q = reinterpret_cast<unsigned long long *>(smem + 8192) + wv * SQ;
-    uint32_t qcount = 0; // wave-uniform
-    auto spill = [&]() __attribute__((always_inline)) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(a.cand_n, (unsigned long long)qcount);
-        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-        const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
-        for (uint32_t i = (uint32_t)lane; i < qcount; i += 64)
-            if (b + i < a.cand_cap) a.cand[b + i] = s_q[i];
-        qcount = 0;
-    };
-    auto push_hits = [&](uint32_t hits, int64_t cc) __attribute__((always_inline)) {
-        const int64_t pos = a.tile0 + cc * 1024 + 16 * lane;
-        while (__builtin_amdgcn_ballot_w64(hits != 0)) { // <= 16 rounds of <= 64 positions
-            const bool has = hits != 0;
-            const int i = has ? __builtin_ctz(hits) : 0;
-            hits &= hits - 1u; // (0 stays 0)
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
-            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (has) s_q[idx] = (unsigned long long)(pos + i);
-            qcount += (uint32_t)__builtin_popcountll(mask);
-            if (qcount >= (uint32_t)(SQ - 64)) spill();
-        }
-    };
-
-    int64_t c = ((int64_t)blockIdx.x * (APM_BLOCK / 64) + wv) * 4; // four neighbouring chunks per wave
-    u32x4 r0, r1, r2, r3;
-    uint2 e0 = make_uint2(0, 0), e1 = e0, e2 = e0, e3 = e0;
-    load_chunk(c, r0, e0);
-    load_chunk(c + 1, r1, e1);
-    load_chunk(c + 2, r2, e2);
-    load_chunk(c + 3, r3, e3);
-    for (; c < nch; c += 4 * W) {
-        uint32_t h0, h1, h2, h3;
-        { const u32x4 v = r0; const uint2 e = e0; load_chunk(c + 4 * W, r0, e0); h0 = hit_bits(v, e, c); }
-        { const u32x4 v = r1; const uint2 e = e1; load_chunk(c + 4 * W + 1, r1, e1); h1 = hit_bits(v, e, c + 1); }
-        { const u32x4 v = r2; const uint2 e = e2; load_chunk(c + 4 * W + 2, r2, e2); h2 = hit_bits(v, e, c + 2); }
-        { const u32x4 v = r3; const uint2 e = e3; load_chunk(c + 4 * W + 3, r3, e3); h3 = hit_bits(v, e, c + 3); }
-        if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j);
-        }
-    }
-    if (qcount) spill();
-}
-hipError_t apm_launch_sieve(const ApmSieveArgs &a, int n_cu, hipStream_t s) {
-    if (a.nchunks <= 0) return hipSuccess;
-    const int64_t want = (a.nchunks + 3) / 4;
-    const int64_t cap = (int64_t)n_cu * 5; // = the kernel's launch bound
-    const int64_t nb = want < cap ? want : cap;
-    ApmSieveArgs args = a;
-#ifdef APM_MEASURE
-    if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
-#endif
-    void *kargs[] = {&args};
-    return hipLaunchKernel((const void *)apm_sieve_kernel, dim3((unsigned)nb), dim3(APM_BLOCK), kargs, 8192 + 4 * 256 * 8, s);
 }
 
 static size_t apm_stream_lds_bytes(const ApmFilterArgs &a) {
@@ -1797,7 +1533,7 @@ hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t
     if (a.ntiles <= 0 || a.n_pats <= 0) return hipSuccess;
     const void *fn = apm_stream_fn(a.band, a.key_len, a.stride);
     if (!fn) return hipErrorInvalidValue;
-    const int64_t want = a.cand_mode == 1 ? max_blocks : (a.ntiles + 3) / 4; // (verify-only: list length unknown here)
+    const int64_t want = (a.ntiles + 3) / 4;
     const int64_t cap = max_blocks < 1 ? 1 : max_blocks;
     const int64_t nb = want < cap ? want : cap;
     ApmFilterArgs args = a;

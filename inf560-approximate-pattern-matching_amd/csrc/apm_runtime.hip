@@ -13,6 +13,7 @@
  */
 #include "../../include/apm.h"
 #include "apm_internal.h"
+#include "apm_sieve.h"
 #include "apm_core.h"
 
 #include <algorithm>
@@ -80,11 +81,33 @@ struct TiledLaunch {       // host description of one tiled scan launch
     int m_max = 0, m_min = 0, tile = 0;
 };
 
-struct SievePlan {         // one text pass (apm_sieve_kernel) shared by all sparse per-position launches
+struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns and its LDS image (apm_sieve.hip)
+    std::vector<ApmPatDesc> descs;    // m, index, byte_off (into bytes), aux_off (into piece_off)
+    std::vector<uint8_t> bytes;       // raw pattern bytes
+    std::vector<uint16_t> piece_off;  // piece offsets, per pattern contiguous
+    std::vector<uint32_t> kinfo;      // per key (id = pattern slot * (k+1) + piece): pat | off << 12 | piece << 21
+    std::vector<uint32_t> pinfo;      // per pattern: {byte_off | m << 16, first piece_off index}
+    std::vector<uint8_t> image;       // bitmap16 | prefix | r2s | slots | kext | pattern bytes
+    int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0;
+    int m_max = 0, m_min = 0;
+    int blocks_per_cu = 0;            // occupancy query, cached
+};
+
+struct SievePlan {         // ONE text pass (apm_sieve2_kernel) for every per-position key of the pattern set
     bool on = false;
     int code_shift = 1;
     int m_max = 0;
-    std::vector<uint8_t> bitmap; // 8 KiB over 8-byte code words
+    double rate = 0;                  // expected hits per even text position on uniform codes (bitmap density)
+    std::vector<uint32_t> bitmap;     // 32 KiB over the 18-bit code words of 9-byte windows: dword x & 8191, bit x >> 13
+    std::vector<VerifyLaunch> launches;
+};
+
+struct DevVerify {
+    ApmPatDesc *d_descs = nullptr;
+    uint8_t *d_image = nullptr;
+    uint32_t *d_kinfo = nullptr;
+    uint32_t *d_pinfo = nullptr;
+    uint16_t *d_poff = nullptr;
 };
 
 struct GenericGroup {      // patterns scanned by the generic kernel, one launch (grid.y = pattern)
@@ -120,8 +143,9 @@ struct DeviceState {
     uint8_t *d_text = nullptr;
     size_t text_cap = 0;
     hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr}; // apm_count_file: staging buffer b copied out (this device's stream)
-    uint8_t *d_sieve_bmp = nullptr;            // sieve bitmap (8 KiB)
-    unsigned long long *d_cand = nullptr;      // sieve candidate list: [0] = counter, [1..] = positions
+    uint32_t *d_sieve_bmp = nullptr;           // sieve bitmap (32 KiB)
+    std::vector<DevVerify> verify;
+    unsigned long long *d_cand = nullptr;      // sieve candidate list: [0] = counter, behind [1]: 32-bit entries (position / 2)
     unsigned long long cand_cap = 0;
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
     bool events_recorded = false;
@@ -267,6 +291,14 @@ void free_device_plan(DeviceState &ds) {
     if (ds.d_trivial) hipFree(ds.d_trivial), ds.d_trivial = nullptr;
     if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
     if (ds.d_sieve_bmp) hipFree(ds.d_sieve_bmp), ds.d_sieve_bmp = nullptr;
+    for (auto &v : ds.verify) {
+        if (v.d_descs) hipFree(v.d_descs);
+        if (v.d_image) hipFree(v.d_image);
+        if (v.d_kinfo) hipFree(v.d_kinfo);
+        if (v.d_pinfo) hipFree(v.d_pinfo);
+        if (v.d_poff) hipFree(v.d_poff);
+    }
+    ds.verify.clear();
 }
 
 template <typename T>
@@ -287,12 +319,15 @@ int upload_vec(apm_ctx *ctx, T **dptr, const std::vector<T> &v) {
 // piece with its partner in front of it (or none) gets.
 // Without the pair pre-check (band 0: k <= 1) a nomination is just "the key bytes match", and the dedup of the
 // kernels relies on exactly that predicate -- so there only the key itself is entered, with every continuation.
-void mark_key_windows(std::vector<uint8_t> &bmp, const TiledLaunch &L, const ApmKey &kk, int pieces, int shift, bool pairs) {
-    const ApmPatDesc &dd = L.descs[kk.pat];
-    auto piece_begin = [&](int q) { return q >= pieces ? (int)dd.m : (int)L.piece_off[dd.aux_off + q]; };
-    auto code = [&](int y) { return (uint32_t)((L.bytes[dd.byte_off + y] >> shift) & 3); };
-    const int q = kk.piece, at = kk.off;
-    const int len = pairs ? piece_begin(q + 1) - at : L.key_len; // (stride 1: the key starts the piece)
+// fn(xx) for every 16-bit code word xx the 8-byte window at the start of piece q may show (see above).
+// pat = the pattern's bytes, poffs = its `pieces` piece offsets, m its length; plain_len = the key length used
+// without the pair pre-check.
+template <typename F>
+void enum_key_windows(const uint8_t *pat, int m, const uint16_t *poffs, int pieces, int q, int plain_len, int shift, bool pairs, F fn) {
+    auto piece_begin = [&](int qq) { return qq >= pieces ? m : (int)poffs[qq]; };
+    auto code = [&](int y) { return (uint32_t)((pat[y] >> shift) & 3); };
+    const int at = piece_begin(q);
+    const int len = pairs ? piece_begin(q + 1) - at : plain_len; // (stride 1: the key starts the piece)
     const int vis = std::min(len, 8), ext = 8 - vis;
     uint32_t x = 0;
     for (int z = 0; z < vis; ++z) x |= code(at + z) << (2 * z);
@@ -319,10 +354,145 @@ void mark_key_windows(std::vector<uint8_t> &bmp, const TiledLaunch &L, const Apm
                 }
             }
         }
-        if (!ok) continue;
-        const uint32_t xx = x | (p << (2 * vis));
-        bmp[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
+        if (ok) fn(x | (p << (2 * vis)));
     }
+}
+
+void mark_key_windows(std::vector<uint8_t> &bmp, const TiledLaunch &L, const ApmKey &kk, int pieces, int shift, bool pairs) {
+    const ApmPatDesc &dd = L.descs[kk.pat];
+    enum_key_windows(L.bytes.data() + dd.byte_off, (int)dd.m, L.piece_off.data() + dd.aux_off, pieces, (int)kk.piece, L.key_len, shift, pairs,
+                     [&](uint32_t xx) { bmp[xx & 8191u] |= (uint8_t)(1u << (xx >> 13)); });
+}
+
+// Plan of the sieve + verify pipeline for all BANDED patterns of the set (see build_plan).  Leaves ctx->sieve.on
+// false when the key set is too dense or does not fit the pipeline's limits.
+int build_sieve_plan(apm_ctx *ctx) {
+    SievePlan &S = ctx->sieve;
+    const int P = (int)ctx->pats.size();
+    const int pieces = ctx->k + 1;
+    const bool pairs = ctx->k / 2 >= 1;
+    std::vector<int> idx;
+    for (int i = 0; i < P; ++i)
+        if (ctx->pats[i].kernel == APM_KERNEL_BANDED) idx.push_back(i);
+    // one code shift for the whole set: spread the pattern bytes over the four 2-bit codes as evenly as possible
+    // (s = 1 separates A,C,G,T and a,c,g,t exactly)
+    long best = -1;
+    for (int sft = 0; sft < 7; ++sft) {
+        long hist[4] = {0, 0, 0, 0};
+        for (int i : idx)
+            for (unsigned char c : ctx->pats[i].bytes) ++hist[(c >> sft) & 3];
+        const long score = std::min(std::min(hist[0], hist[1]), std::min(hist[2], hist[3])) * 4 +
+                           (hist[0] > 0) + (hist[1] > 0) + (hist[2] > 0) + (hist[3] > 0) + (sft == 1);
+        if (score > best) { best = score; S.code_shift = sft; }
+    }
+    S.bitmap.assign(8192, 0u);
+    std::vector<uint8_t> seen16(8192, 0); // union of the launches' 16-bit code words (byte x & 8191, bit x >> 13)
+    for (size_t pos = 0; pos < idx.size();) {
+        VerifyLaunch V;
+        for (; pos < idx.size(); ++pos) {
+            const PatternInfo &pi = ctx->pats[idx[pos]];
+            if (!V.descs.empty() && (V.bytes.size() + (size_t)pi.m > 24576 || V.kinfo.size() + (size_t)pieces > 8192 || V.descs.size() >= 4096))
+                break;
+            ApmPatDesc d{};
+            d.m = (uint32_t)pi.m;
+            d.index = (uint32_t)idx[pos];
+            d.byte_off = (uint32_t)V.bytes.size();
+            d.aux_off = (uint32_t)V.piece_off.size();
+            d.w = (uint32_t)pieces;
+            V.bytes.insert(V.bytes.end(), pi.bytes.begin(), pi.bytes.end());
+            for (int q = 0; q < pieces; ++q) {
+                const int aq = (int)((int64_t)q * pi.m / pieces);
+                V.piece_off.push_back((uint16_t)aq);
+                V.kinfo.push_back((uint32_t)V.descs.size() | ((uint32_t)aq << 12) | ((uint32_t)q << 21));
+            }
+            V.pinfo.push_back(d.byte_off | (d.m << 16));
+            V.pinfo.push_back(d.aux_off);
+            V.descs.push_back(d);
+            V.m_max = std::max(V.m_max, pi.m);
+            V.m_min = V.m_min ? std::min(V.m_min, pi.m) : pi.m;
+        }
+        while (V.bytes.size() % 16) V.bytes.push_back(0);
+        // (code word, key) pairs in rank order: the verify kernel keeps the words as dword x & 2047, bit x >> 11
+        auto rank_key = [](uint32_t x) { return ((x & 2047u) << 5) | (x >> 11); };
+        std::vector<uint64_t> wk;
+        std::vector<uint32_t> kext;
+        for (size_t ps = 0; ps < V.descs.size(); ++ps) {
+            const ApmPatDesc &dd = V.descs[ps];
+            const uint8_t *pat = V.bytes.data() + dd.byte_off;
+            const uint16_t *poffs = V.piece_off.data() + dd.aux_off;
+            auto piece_begin = [&](int q) { return q >= pieces ? (int)dd.m : (int)poffs[q]; };
+            for (int q = 0; q < pieces; ++q) {
+                const uint32_t kid = (uint32_t)(ps * (size_t)pieces + (size_t)q);
+                const int len = piece_begin(q + 1) - piece_begin(q);
+                enum_key_windows(pat, (int)dd.m, poffs, pieces, q, len, S.code_shift, pairs,
+                                 [&](uint32_t xx) { wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | kid); });
+                const int pq = q ^ 1;
+                uint32_t side = 0, plen = 0;
+                if (pairs && pq < pieces) {
+                    side = pq > q ? 1u : 2u;
+                    plen = (uint32_t)(piece_begin(pq + 1) - piece_begin(pq));
+                }
+                kext.push_back((uint32_t)(dd.byte_off + (uint32_t)piece_begin(q)) | (std::min<uint32_t>((uint32_t)len, 255u) << 16) |
+                               ((plen > 16 ? 31u : plen) << 24) | (side << 29));
+            }
+        }
+        std::sort(wk.begin(), wk.end());
+        wk.erase(std::unique(wk.begin(), wk.end()), wk.end());
+        std::vector<uint32_t> bmp16(2048, 0u);
+        std::vector<uint16_t> prefix(2048, 0), r2s, slots;
+        for (size_t i = 0; i < wk.size();) {
+            size_t j = i;
+            while (j < wk.size() && (wk[j] >> 32) == (wk[i] >> 32)) ++j;
+            const uint32_t xx = (uint32_t)(wk[i] >> 16) & 0xffffu;
+            bmp16[xx & 2047u] |= 1u << (xx >> 11);
+            seen16[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
+            if (j - i == 1) {
+                r2s.push_back((uint16_t)(0x8000u | (wk[i] & 0x7fffu)));
+            } else {
+                r2s.push_back((uint16_t)slots.size());
+                for (size_t z = i; z < j; ++z) slots.push_back((uint16_t)((wk[z] & 0x7fffu) | (z + 1 == j ? 0x8000u : 0u)));
+            }
+            i = j;
+        }
+        if (r2s.size() > 6553 || slots.size() >= 0x8000) return APM_OK; // too dense for a list-driven pass: tile kernels
+        uint32_t run = 0;
+        for (int w = 0; w < 2048; ++w) {
+            prefix[w] = (uint16_t)run;
+            run += (uint32_t)__builtin_popcount(bmp16[w]);
+        }
+        auto append = [&](const void *src, size_t bytes) {
+            const size_t at = V.image.size();
+            V.image.resize(at + ((bytes + 15) & ~(size_t)15), 0);
+            if (bytes) memcpy(V.image.data() + at, src, bytes);
+            return (int)at;
+        };
+        append(bmp16.data(), bmp16.size() * 4); // = 0
+        V.o_prefix = append(prefix.data(), prefix.size() * 2);
+        V.o_r2s = append(r2s.data(), r2s.size() * 2);
+        V.o_slots = append(slots.data(), slots.size() * 2);
+        V.o_kext = append(kext.data(), kext.size() * 4);
+        V.o_pat = append(V.bytes.data(), V.bytes.size());
+        S.m_max = std::max(S.m_max, V.m_max);
+        S.launches.push_back(std::move(V));
+    }
+    // the sieve's bitmap over 9-byte windows at EVEN positions: a key window (16-bit word x) may start at the even
+    // position (then the ninth byte is free) or at the odd one behind it (then the first byte is free)
+    long pop16 = 0, pop18 = 0;
+    for (uint32_t x = 0; x < 65536u; ++x) {
+        if (!((seen16[x & 8191u] >> (x >> 13)) & 1u)) continue;
+        ++pop16;
+        for (uint32_t f = 0; f < 4; ++f) {
+            for (const uint32_t c18 : {x | (f << 16), (x << 2) | f}) {
+                uint32_t &w = S.bitmap[c18 & 8191u];
+                pop18 += !((w >> (c18 >> 13)) & 1u);
+                w |= 1u << (c18 >> 13);
+            }
+        }
+    }
+    if (pop16 > 6553) return APM_OK;
+    S.rate = (double)pop18 / 262144.0;
+    S.on = !S.launches.empty();
+    return APM_OK;
 }
 
 int build_plan(apm_ctx *ctx) {
@@ -443,25 +613,23 @@ int build_plan(apm_ctx *ctx) {
         }
     }
 
-    // ---- sieve decision: if the per-position classes with 6..14-byte pieces are sparse (few keys per
-    // 4^key_len code words) and the band is narrow, ONE sieve pass over the text feeds all of them, and the
-    // patterns with longer pieces join the 8-byte per-position class (one key per piece instead of a
-    // sampled family, tested at every position anyway) so that no separate pass remains for them.
-    // APM_SIEVE=0 switches it off (A/B aid). ----
+    // ---- sieve + verify pipeline (apm_sieve.hip): as soon as one BANDED pattern needs every text position looked at
+    // (pieces shorter than 15 bytes), ONE sieve pass serves all BANDED patterns of the set -- those with longer
+    // pieces join with one key per piece instead of a sampled family -- and the verify launches work off its
+    // candidate list.  The LDS-tile / stream launches of the same patterns are still planned below: they run as
+    // device-guarded fallbacks (candidate list overflow) and for text the sieve cannot take (unaligned, >= 4 GiB).
+    // Too dense a key set (more than a tenth of all 8-byte code words) stays on the tile kernels.
+    // APM_SIEVE=0 switches the pipeline off (A/B aid). ----
     ctx->sieve = SievePlan();
     {
         static const int sieve_env = getenv("APM_SIEVE") ? atoi(getenv("APM_SIEVE")) : 1;
-        long n8 = 0, n6 = 0, n_long = 0;
         bool has_s1 = false;
-        for (int i = 0; i < P; ++i) {
-            if (ctx->pats[i].kernel != APM_KERNEL_BANDED) continue;
-            const int piece = ctx->pats[i].m / (ctx->k + 1);
-            if (piece >= 15) n_long += ctx->k + 1;
-            else if (piece >= 8) n8 += ctx->k + 1, has_s1 = true;
-            else if (piece >= 6) n6 += ctx->k + 1, has_s1 = true;
+        for (int i = 0; i < P; ++i)
+            if (ctx->pats[i].kernel == APM_KERNEL_BANDED && ctx->pats[i].m / (ctx->k + 1) < 15) has_s1 = true;
+        if (sieve_env && has_s1) {
+            const int rc = build_sieve_plan(ctx);
+            if (rc) return rc;
         }
-        const double rate = (double)(n8 + n_long) / 65536.0 + (double)n6 / 4096.0;
-        ctx->sieve.on = sieve_env && has_s1 && ctx->k / 2 <= 1 && rate < 1.0 / 200.0;
     }
 
     // ---- BANDED launches: patterns grouped by (key length, sampling stride); k+1 pigeonhole pieces each ----
@@ -471,7 +639,7 @@ int build_plan(apm_ctx *ctx) {
         const int stride = st_of[cls];
         auto class_of = [&](int m) {
             const int piece = m / (ctx->k + 1);
-            if (ctx->sieve.on && piece >= 8) return 2;
+            if (ctx->sieve.on && piece >= 8) return 2; // (same coverage as the sieve pipeline: these launches are its fallback)
             return piece >= 31 ? 0 : (piece >= 15 ? 1 : (piece >= 8 ? 2 : (piece >= 6 ? 3 : 4)));
         };
         std::vector<int> idx;
@@ -489,7 +657,7 @@ int build_plan(apm_ctx *ctx) {
             L.kind = APM_KERNEL_BANDED;
             L.key_len = klen;
             L.stride = stride;
-            L.sieved = ctx->sieve.on && (cls == 2 || cls == 3);
+            L.sieved = ctx->sieve.on && stride == 1;
             L.qcap = stride == 1 ? 1024 : 512;
             memset(L.lut, 0, sizeof L.lut);
             const int pieces = ctx->k + 1;
@@ -659,28 +827,6 @@ int build_plan(apm_ctx *ctx) {
         }
     }
 
-    // ---- sieve bitmap: every key of the sieved launches, as 8-byte code words under ONE code shift ----
-    if (ctx->sieve.on) {
-        SievePlan &S = ctx->sieve;
-        long best = -1;
-        for (int sft = 0; sft < 7; ++sft) {
-            long hist[4] = {0, 0, 0, 0};
-            for (const TiledLaunch &L : ctx->tiled)
-                if (L.sieved)
-                    for (const ApmPatDesc &dd : L.descs)
-                        for (uint32_t y = 0; y < dd.m; ++y) ++hist[(L.bytes[dd.byte_off + y] >> sft) & 3];
-            const long score = std::min(std::min(hist[0], hist[1]), std::min(hist[2], hist[3])) * 4 +
-                               (hist[0] > 0) + (hist[1] > 0) + (hist[2] > 0) + (hist[3] > 0) + (sft == 1);
-            if (score > best) { best = score; S.code_shift = sft; }
-        }
-        S.bitmap.assign(8192, 0);
-        for (const TiledLaunch &L : ctx->tiled) {
-            if (!L.sieved) continue;
-            S.m_max = std::max(S.m_max, L.m_max);
-            for (const ApmKey &kk : L.keys) mark_key_windows(S.bitmap, L, kk, ctx->k + 1, S.code_shift, ctx->k / 2 >= 1);
-        }
-    }
-
     // ---- upload to every device ----
     for (auto &ds : ctx->devs) {
         free_device_plan(ds);
@@ -692,7 +838,18 @@ int build_plan(apm_ctx *ctx) {
         if ((rc = upload_vec(ctx, &ds.d_long_descs, ctx->longs.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_trivial, ctx->trivial))) return rc;
         HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
-        if (ctx->sieve.on && (rc = upload_vec(ctx, &ds.d_sieve_bmp, ctx->sieve.bitmap))) return rc;
+        if (ctx->sieve.on) {
+            if ((rc = upload_vec(ctx, &ds.d_sieve_bmp, ctx->sieve.bitmap))) return rc;
+            ds.verify.resize(ctx->sieve.launches.size());
+            for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
+                const VerifyLaunch &V = ctx->sieve.launches[v];
+                if ((rc = upload_vec(ctx, &ds.verify[v].d_descs, V.descs))) return rc;
+                if ((rc = upload_vec(ctx, &ds.verify[v].d_image, V.image))) return rc;
+                if ((rc = upload_vec(ctx, &ds.verify[v].d_kinfo, V.kinfo))) return rc;
+                if ((rc = upload_vec(ctx, &ds.verify[v].d_pinfo, V.pinfo))) return rc;
+                if ((rc = upload_vec(ctx, &ds.verify[v].d_poff, V.piece_off))) return rc;
+            }
+        }
         ds.tiled.resize(ctx->tiled.size());
         for (size_t t = 0; t < ctx->tiled.size(); ++t) {
             const TiledLaunch &L = ctx->tiled[t];
@@ -800,38 +957,90 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     }
 
     if (ctx->timing_on) HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
-    // the sieve pass of the sparse per-position launches (needs the 16-byte aligned text the stream kernels need)
+    // sieve + verify pipeline of the per-position classes (needs 16-byte aligned text and < 4 GiB of it: 32-bit
+    // buffer offsets, 32-bit list entries); otherwise the LDS-tile / stream launches below do the whole job
     bool sieve_run = false;
     if (ctx->sieve.on && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0) {
         const int band = ctx->k / 2;
         const int64_t avail_pad = avail + (int64_t)((16u - ((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)avail) & 15u)) & 15u);
         const int64_t p_lo = std::max<int64_t>(0, jb - band) & ~(int64_t)15;
         const int64_t p_hi = std::min<int64_t>(avail, je + ctx->sieve.m_max + band);
-        if (p_hi > p_lo && avail_pad >= 16) {
-            // list capacity: 1/64 of the scanned positions (3x the rate the plan admits), 64 Ki .. 64 Mi entries
-            unsigned long long want = std::min<unsigned long long>(64ull << 20, std::max<unsigned long long>(64ull << 10, (unsigned long long)(p_hi - p_lo) / 64));
+        if (p_hi > p_lo && avail_pad >= 16 && avail_pad < ((int64_t)1 << 32) - 4096) {
+            // list capacity: 1.5 x the hits expected on uniform codes + 1/256 of the positions, 64 Ki .. 1 Gi entries
+            const double expect = (double)(p_hi - p_lo) * 0.5 * ctx->sieve.rate;
+            unsigned long long want = (unsigned long long)(1.5 * expect) + (unsigned long long)(p_hi - p_lo) / 256;
+            want = std::min<unsigned long long>(1ull << 30, std::max<unsigned long long>(64ull << 10, want));
             static const long cap_env = getenv("APM_SIEVE_CAP") ? atol(getenv("APM_SIEVE_CAP")) : 0; // test hook: force the overflow fallback
             if (cap_env > 0) want = (unsigned long long)cap_env;
+            want = (want + APM_CAND_SHARDS - 1) / APM_CAND_SHARDS * APM_CAND_SHARDS; // equal regions
+            const size_t hdr = 64 + (size_t)APM_CAND_SHARDS * 128; // overflow flag + one counter per region, 128 bytes apart
             if (ds.cand_cap != want && (ds.cand_cap < want || cap_env > 0)) {
-                if (ds.d_cand) HIP_TRY(ctx, hipFree(ds.d_cand));
+                if (ds.d_cand) {
+                    HIP_TRY(ctx, hipStreamSynchronize(ds.stream)); // (a verify launch of an earlier call may still read it)
+                    HIP_TRY(ctx, hipFree(ds.d_cand));
+                }
                 ds.d_cand = nullptr;
                 ds.cand_cap = 0;
-                HIP_TRY(ctx, hipMalloc((void **)&ds.d_cand, (size_t)(want + 2) * 8));
+                HIP_TRY(ctx, hipMalloc((void **)&ds.d_cand, hdr + (size_t)want * 4 + 16));
                 ds.cand_cap = want;
             }
-            HIP_TRY(ctx, hipMemsetAsync(ds.d_cand, 0, 16, ds.stream));
-            ApmSieveArgs sv{};
+            HIP_TRY(ctx, hipMemsetAsync(ds.d_cand, 0, hdr, ds.stream));
+            ApmSieve2Args sv{};
             sv.text = d_text;
             sv.avail_pad = avail_pad;
             sv.tile0 = p_lo;
             sv.nchunks = (p_hi - p_lo + 1023) / 1024;
             sv.bitmap = reinterpret_cast<const uint4 *>(ds.d_sieve_bmp);
             sv.code_shift = ctx->sieve.code_shift;
-            sv.cand = ds.d_cand + 2;
+            sv.cand = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ds.d_cand) + hdr);
+            sv.shard_cnt = ds.d_cand + 8;
+            sv.shard_cap = ds.cand_cap / APM_CAND_SHARDS;
             sv.cand_n = ds.d_cand;
             sv.cand_cap = ds.cand_cap;
-            HIP_TRY(ctx, apm_launch_sieve(sv, ds.n_cu, ds.stream));
+            if (tails_pending) { // the truncated tail windows ride as extra workgroups beside the scan
+                sv.n_tail = (int)ctx->stails.descs.size();
+                sv.tail = ta;
+                tails_pending = false;
+            }
+            HIP_TRY(ctx, apm_launch_sieve2(sv, ds.n_cu, ds.stream));
             { const int nrc = note_launch(ctx, ds, "sieve"); if (nrc) return nrc; }
+            for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
+                VerifyLaunch &V = ctx->sieve.launches[v];
+                const int64_t je_v = std::min<int64_t>(je, nrel - V.m_min + 1);
+                if (je_v <= jb) continue;
+                ApmVerifyArgs va{};
+                va.text = d_text;
+                va.avail = avail;
+                va.avail_pad = avail_pad;
+                va.jb = jb;
+                va.je = je_v;
+                va.nrel = nrel;
+                va.image = reinterpret_cast<const uint4 *>(ds.verify[v].d_image);
+                va.image_len = (int)V.image.size();
+                va.o_prefix = V.o_prefix;
+                va.o_r2s = V.o_r2s;
+                va.o_slots = V.o_slots;
+                va.o_kext = V.o_kext;
+                va.o_pat = V.o_pat;
+                va.kinfo = ds.verify[v].d_kinfo;
+                va.pinfo = reinterpret_cast<const uint2 *>(ds.verify[v].d_pinfo);
+                va.poff = ds.verify[v].d_poff;
+                va.pats = ds.verify[v].d_descs;
+                va.counts = d_counts;
+                va.n_pats = (int)V.descs.size();
+                va.nk = (int)V.kinfo.size();
+                va.k = ctx->k;
+                va.band = band;
+                va.code_shift = ctx->sieve.code_shift;
+                va.cand = sv.cand;
+                va.shard_cnt = sv.shard_cnt;
+                va.shard_cap = sv.shard_cap;
+                va.cand_n = sv.cand_n;
+                va.cand_cap = sv.cand_cap;
+                if (!V.blocks_per_cu) V.blocks_per_cu = apm_verify_blocks_per_cu(va);
+                HIP_TRY(ctx, apm_launch_verify(va, ds.n_cu * V.blocks_per_cu, ds.stream));
+                { const int nrc = note_launch(ctx, ds, "verify"); if (nrc) return nrc; }
+            }
             sieve_run = true;
         }
     }
@@ -892,9 +1101,14 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             // per-position classes stream only when candidates are expected to be rare (verification then
             // reads global text, dense 64-candidate batches); APM_FILTER_STREAM=2 forces, 3 forbids (A/B aid)
             const double hit_rate = (double)L.keys.size() / (double)(1ull << (2 * std::min(L.key_len, 8)));
-            const bool sieved = sieve_run && L.sieved;
-            const bool stream_ok = sieved || L.stride > 1 || (f.band <= 1 && (stream_env == 2 || (stream_env != 3 && hit_rate < 1.0 / 200.0)));
-            if ((stream_env || sieved) && stream_ok && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
+            const bool sieved = sieve_run && L.sieved; // covered by the pipeline above: this launch only guards against list overflow
+            if (sieved) {
+                f.cand_n = ds.d_cand;
+                f.cand_cap = ds.cand_cap;
+                f.cand_mode = 2;
+            }
+            const bool stream_ok = L.stride > 1 || (f.band <= 1 && (sieved || stream_env == 2 || (stream_env != 3 && hit_rate < 1.0 / 200.0)));
+            if (stream_env && stream_ok && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
                 // wave-autonomous streaming kernel over 1 KiB chunks
                 const int64_t p_lo = std::max<int64_t>(0, jb - f.band) & ~(int64_t)15;
                 const int64_t p_hi = std::min<int64_t>(avail, je_l + L.m_max + f.band);
@@ -906,18 +1120,8 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                     f.tail = ta;
                     tails_pending = false;
                 }
-                if (sieved) { // verify-only over the sieve's list, then the guarded fallback (a no-op unless the list overflowed)
-                    f.cand = ds.d_cand + 2;
-                    f.cand_n = ds.d_cand;
-                    f.cand_cap = ds.cand_cap;
-                    f.cand_mode = 1;
-                    HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
-                    { const int nrc = note_launch(ctx, ds, "stream(verify-only)"); if (nrc) return nrc; }
-                    f.n_tail = 0; // (the tail workgroups ran with the launch above)
-                    f.cand_mode = 2;
-                }
                 HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
-                { const int nrc = note_launch(ctx, ds, (f.cand_mode == 2 ? "stream(fallback)" : "stream")); if (nrc) return nrc; }
+                { const int nrc = note_launch(ctx, ds, sieved ? "stream(fallback)" : "stream"); if (nrc) return nrc; }
                 continue;
             }
             if (!ctx->tiled[t].blocks_per_cu[f.use_dma])
@@ -936,7 +1140,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
 #endif
                 HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * bpc, ds.stream));
             }
-            { const int nrc = note_launch(ctx, ds, "tile"); if (nrc) return nrc; }
+            { const int nrc = note_launch(ctx, ds, f.cand_mode == 2 ? "tile(fallback)" : "tile"); if (nrc) return nrc; }
             continue;
         }
         ApmScanArgs a{};
@@ -1581,6 +1785,32 @@ int apm_get_launch_times(const apm_ctx *cctx, int max, double *ms, const char **
         if (labels) labels[i] = ds.launch_label[i];
     }
     return n;
+}
+
+int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
+    apm_ctx *ctx = const_cast<apm_ctx *>(cctx);
+    if (!ctx || !name || !value || ctx->devs.empty()) return APM_ERR_INVALID;
+    DeviceState &ds = ctx->devs[0];
+    const std::string n = name;
+    if (n == "sieve_on") { *value = ctx->sieve.on ? 1 : 0; return APM_OK; }
+    if (n == "sieve_rate") { *value = ctx->sieve.rate; return APM_OK; }
+    if (n == "sieve_capacity") { *value = (double)ds.cand_cap; return APM_OK; }
+    if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }
+    if (n == "verify_image_bytes") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].image.size(); return APM_OK; }
+    if (n == "verify_blocks_per_cu") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].blocks_per_cu; return APM_OK; }
+    if (n == "sieve_candidates" || n == "sieve_overflow") { // of the last call (synchronises with the stream)
+        if (!ds.d_cand) { *value = 0; return APM_OK; }
+        HIP_TRY(ctx, hipSetDevice(ds.dev));
+        HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+        std::vector<unsigned long long> h(8 + 16 * APM_CAND_SHARDS);
+        HIP_TRY(ctx, hipMemcpy(h.data(), ds.d_cand, h.size() * 8, hipMemcpyDeviceToHost));
+        if (n == "sieve_overflow") { *value = h[0] > ds.cand_cap ? 1 : 0; return APM_OK; }
+        double sum = 0;
+        for (int i = 0; i < APM_CAND_SHARDS; ++i) sum += (double)h[8 + 16 * (size_t)i];
+        *value = sum;
+        return APM_OK;
+    }
+    return fail(ctx, APM_ERR_INVALID, "unknown statistic '%s'", name);
 }
 
 int apm_device_alloc(apm_ctx *ctx, void **d_ptr, uint64_t bytes) {

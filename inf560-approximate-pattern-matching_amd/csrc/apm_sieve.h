@@ -1,0 +1,78 @@
+/*
+ * apm_sieve.h -- launch arguments of the sieve + verify pipeline (apm_sieve.hip), shared with the runtime only.
+ */
+#ifndef APM_SIEVE_H
+#define APM_SIEVE_H
+
+#include "apm_internal.h"
+
+/* ---- sieve + verify pipeline of the per-position classes (apm_sieve.hip) ----------------------------------
+ * SIEVE: ONE pass over the text for all per-position keys of a pattern set.  Every EVEN text position is tested
+ * with one LDS lookup: the 2-bit codes (b >> code_shift) & 3 of the 9 bytes at the position form an 18-bit code
+ * word x; its bit sits in dword x & 8191, bit x >> 13 of a 32 KiB presence bitmap.  The bitmap holds every code
+ * word under which a key can start at the position itself or at the odd position behind it (host: built from the
+ * 16-bit code words of the keys' 8-byte windows), so one lookup decides two text positions.  Hits are appended
+ * to a global candidate list as (relative position / 2), 32 bits each.
+ * VERIFY: list-driven, one candidate per lane: identifies the key(s) through a rank structure over the exact
+ * 16-bit presence bitmap (no hashing), runs the piece compare + pair pre-check against global text, collects the
+ * survivors per wave and runs the banded DP with stateless dedup on dense lanes. */
+struct ApmSieve2Args {
+    const uint8_t *text;        /* 16-byte aligned */
+    int64_t avail_pad;          /* bytes readable from text (multiple of 16), < 2^32 */
+    int64_t tile0;              /* first scanned relative position (multiple of 16) */
+    int64_t nchunks;            /* 1 KiB chunks */
+    const uint4 *bitmap;        /* 32 KiB */
+    int code_shift;
+    /* candidate list: relative position >> 1, 32 bits each, in APM_CAND_SHARDS regions of shard_cap entries.  A
+       workgroup appends to region blockIdx & (SHARDS-1) through that region's own counter (128 bytes apart: one
+       shared counter would serialise the appends, ~88 per microsecond chip-wide).  A region that runs full raises
+       *cand_n above cand_cap: the verify launches then do nothing and the guarded fallback launches scan. */
+    uint32_t *cand;
+    unsigned long long *shard_cnt; /* counter of shard s at shard_cnt[16 * s] */
+    unsigned long long shard_cap;
+    unsigned long long *cand_n;
+    unsigned long long cand_cap;
+    int n_main_blocks;          /* set by the launcher: scanning workgroups */
+    int n_tail;                 /* extra workgroups, one per pattern with truncated tail windows (they run beside the scan) */
+    ApmTailArgs tail;
+#ifdef APM_MEASURE
+    int skip_mask;
+#endif
+};
+#define APM_CAND_SHARDS 256
+
+struct ApmVerifyArgs {
+    const uint8_t *text;        /* 16-byte aligned */
+    int64_t avail;              /* valid text bytes */
+    int64_t avail_pad;          /* readable bytes (multiple of 16), < 2^32 */
+    int64_t jb, je, nrel;       /* window starts to decide [jb, je); end of the whole text (relative) */
+    /* LDS image (16-byte aligned parts): bitmap over the 16-bit code words of 8-byte windows (dword x & 2047,
+       bit x >> 11) | prefix: u16[2048] set bits in the dwords before | r2s: u16 per set bit (rank order):
+       0x8000 | kid for a single key, else first index into slots | slots: u16 kid, bit 15 = last of its list |
+       kext: u32 per key (see ApmFilterArgs::o_kext) | raw pattern bytes */
+    const uint4 *image;
+    int image_len, o_prefix, o_r2s, o_slots, o_kext, o_pat;
+    /* the records only the (rare) banded DP needs stay in global memory */
+    const uint32_t *kinfo;      /* per key: pat | off << 12 | piece << 21 */
+    const uint2 *pinfo;         /* per pattern: {byte_off | m << 16, first piece-offset index}; key id = pat * (k+1) + piece */
+    const uint16_t *poff;       /* piece offsets */
+    const ApmPatDesc *pats;     /* index = counts[] slot */
+    unsigned long long *counts;
+    int n_pats, nk, k, band, code_shift;
+    const uint32_t *cand;       /* see ApmSieve2Args */
+    const unsigned long long *shard_cnt;
+    unsigned long long shard_cap;
+    const unsigned long long *cand_n;
+    unsigned long long cand_cap;
+    int n_blocks;               /* set by the launcher */
+#ifdef APM_MEASURE
+    int skip_mask;
+#endif
+};
+
+hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s);
+hipError_t apm_launch_verify(const ApmVerifyArgs &a, int max_blocks, hipStream_t s);
+size_t apm_verify_lds_bytes(const ApmVerifyArgs &a);
+int apm_verify_blocks_per_cu(const ApmVerifyArgs &a);
+
+#endif /* APM_SIEVE_H */

@@ -1,0 +1,467 @@
+/*
+ * apm_sieve.hip -- SIEVE + VERIFY: the pipeline of the per-position key classes of the BANDED path
+ * (exact for the predicate dist <= k of the reference's window DP, /root/reference/src/utils.c:76-99 applied at
+ * every text position by /root/reference/src/sequential.c:105-144; the lemmas are stated in apm_kernels.hip).
+ *
+ *   apm_sieve2_kernel   one HBM pass over the text, wave-autonomous (no LDS text tile, no barrier in the loop):
+ *                       1 KiB chunks, 16 bytes per lane (+ the 8 that follow), four chunks in flight per wave.
+ *                       The lane's 24 bytes become a 48-bit string of 2-bit codes (v_dot4_u32_u8 packs four
+ *                       codes per instruction); every EVEN position's 18-bit code word (9 bytes) is one lookup in
+ *                       a 32 KiB LDS presence bitmap that answers for the position and the odd one behind it.
+ *                       Hits leave for a global candidate list through a wave-private LDS queue, one global
+ *                       atomic per >= 128 hits.
+ *   apm_verify_kernel   list-driven: one candidate per lane, 64 per wave and batch.  Key identification by rank
+ *                       over the exact 16-bit presence bitmap (two dependent LDS reads, no hashing, no tags),
+ *                       piece compare + pair pre-check against global text (bounds-checked buffer loads), the
+ *                       survivors of a wave are collected and the banded DP + stateless dedup run on dense lanes.
+ *
+ * Both need a 16-byte aligned text pointer and a shard of < 4 GiB; the runtime falls back to the LDS-tile
+ * kernels of apm_kernels.hip otherwise, and (guarded on the device) when the candidate list overflows.
+ */
+#include "apm_device.h"
+#include "apm_sieve.h"
+
+typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t apm_lds_u32; // LDS dword, for constant-base accesses
+
+#define APM_SIEVE2_BLOCK 512
+#define APM_SIEVE2_QUEUE 192 /* queue entries per wave: spilled to the list once it holds >= 128 */
+
+__device__ __forceinline__ uint32_t apm_udot4(uint32_t a, uint32_t b) {
+    return __builtin_amdgcn_udot4(a, b, 0u, false); // v_dot4_u32_u8
+}
+
+// ---------------------------------------------------------------------------
+// SIEVE
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSieve2Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= a.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
+        apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
+        return;
+    }
+    for (int i = tid; i < 2048; i += APM_SIEVE2_BLOCK) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
+    __syncthreads();
+    const int64_t W = (int64_t)a.n_main_blocks * (APM_SIEVE2_BLOCK / 64);
+    const int64_t nch = a.nchunks;
+
+    auto load_chunk = [&](int64_t cc, u32x4 &r, v2u32 &e) __attribute__((always_inline)) {
+        const int64_t g = a.tile0 + cc * 1024;
+        const int64_t lim = cc < nch ? a.avail_pad - g : 0; // chunks past the end: zero records -> zeros, no traffic
+        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1040 ? 1040u : (uint32_t)lim);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+        e = __builtin_amdgcn_raw_buffer_load_b64(rs, 16 * lane + 16, 0, 0);
+    };
+    // 4 bytes -> 8 code bits (byte z in bits 2z..): shift + and + one v_dot4_u32_u8 with the byte weights 1, 4, 16, 64
+    const uint32_t cs = (uint32_t)a.code_shift;
+    auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
+    // the bitmap leads this kernel's LDS (no static LDS, checked by the tests): LDS address = the masked code bits
+    // hit mask of the lane's eight even positions: bit 24 + t = position 2t
+    auto hit_bits = [&](const u32x4 &v, const v2u32 &e, int64_t cc) __attribute__((always_inline)) {
+        const uint32_t slo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24); // codes of bytes 0..15
+        const uint32_t shi = pack4(e.x) | (pack4(e.y) << 8);                                           // bytes 16..23
+        uint32_t hits = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            // y: the 18-bit code word of position 2t in bits 2..19 -> byte address of its bitmap dword = y & 0x7ffc,
+            // bit index = bits 15..19 (a shift by a VGPR uses its low five bits)
+            const uint32_t y = t ? __builtin_amdgcn_alignbit(shi, slo, 4u * (uint32_t)t - 2u) : (slo << 2);
+            const uint32_t word = *(const apm_lds_u32 *)(uintptr_t)(y & 0x7ffcu);
+            hits = __builtin_amdgcn_alignbit(word >> ((y >> 15) & 31u), hits, 1u); // bit 0 of the shifted word enters at the top
+        }
+#ifdef APM_MEASURE
+        if (APM_SKIP(a, 1)) hits = 0;
+#endif
+        return cc < nch ? hits : 0u;
+    };
+    // hit positions are staged in a wave-private LDS queue (ballot + mbcnt, no atomics) and leave for the
+    // global list 128+ at a time: one global atomic per batch, not per hit
+    uint32_t *s_q = reinterpret_cast<uint32_t *>(smem + 32768) + wv * APM_SIEVE2_QUEUE;
+    uint32_t qcount = 0; // wave-uniform
+    const uint32_t shard = blockIdx.x & (APM_CAND_SHARDS - 1);
+    unsigned long long *const scnt = a.shard_cnt + 16u * shard;
+    uint32_t *const sbase = a.cand + (size_t)shard * (size_t)a.shard_cap;
+    auto spill = [&]() __attribute__((always_inline)) {
+        unsigned long long base = 0;
+        if (lane == 0) {
+            base = atomicAdd(scnt, (unsigned long long)qcount);
+            if (base + qcount > a.shard_cap) atomicMax(a.cand_n, a.cand_cap + 1ull); // region full: flag the overflow
+        }
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
+        for (uint32_t i = (uint32_t)lane; i < qcount; i += 64)
+            if (b + i < a.shard_cap) sbase[b + i] = s_q[i];
+        qcount = 0;
+    };
+    auto push_hits = [&](uint32_t hits, int64_t cc) __attribute__((always_inline)) {
+        const uint32_t half = (uint32_t)((a.tile0 + cc * 1024) >> 1) + 8u * (uint32_t)lane; // (relative position of the lane's byte 0) / 2
+        while (__builtin_amdgcn_ballot_w64(hits != 0)) { // <= 8 rounds of <= 64 positions
+            const bool has = hits != 0;
+            const uint32_t t = has ? (uint32_t)__builtin_ctz(hits) - 24u : 0u;
+            hits &= hits - 1u; // (0 stays 0)
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (has) s_q[idx] = half + t;
+            qcount += (uint32_t)__builtin_popcountll(mask);
+            if (qcount >= (uint32_t)(APM_SIEVE2_QUEUE - 64)) spill();
+        }
+    };
+
+    int64_t c = ((int64_t)blockIdx.x * (APM_SIEVE2_BLOCK / 64) + wv) * 4; // four neighbouring chunks per wave
+    u32x4 r0, r1, r2, r3;
+    v2u32 e0, e1, e2, e3;
+    load_chunk(c, r0, e0);
+    load_chunk(c + 1, r1, e1);
+    load_chunk(c + 2, r2, e2);
+    load_chunk(c + 3, r3, e3);
+    for (; c < nch; c += 4 * W) {
+        uint32_t h0, h1, h2, h3;
+        { const u32x4 v = r0; const v2u32 e = e0; load_chunk(c + 4 * W, r0, e0); h0 = hit_bits(v, e, c); }
+        { const u32x4 v = r1; const v2u32 e = e1; load_chunk(c + 4 * W + 1, r1, e1); h1 = hit_bits(v, e, c + 1); }
+        { const u32x4 v = r2; const v2u32 e = e2; load_chunk(c + 4 * W + 2, r2, e2); h2 = hit_bits(v, e, c + 2); }
+        { const u32x4 v = r3; const v2u32 e = e3; load_chunk(c + 4 * W + 3, r3, e3); h3 = hit_bits(v, e, c + 3); }
+        if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j);
+        }
+    }
+    if (qcount) spill();
+}
+
+hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
+    if (a.nchunks <= 0) return hipSuccess;
+    const size_t lds = 32768 + (size_t)(APM_SIEVE2_BLOCK / 64) * APM_SIEVE2_QUEUE * 4;
+    const int64_t want = (a.nchunks + 4 * (APM_SIEVE2_BLOCK / 64) - 1) / (4 * (APM_SIEVE2_BLOCK / 64));
+    const int64_t cap = (int64_t)n_cu * 4; // = the kernel's launch bound (4 x 512 threads per CU; 4 x 38 KB of LDS)
+    const int64_t nb = want < cap ? want : cap;
+    ApmSieve2Args args = a;
+    args.n_main_blocks = (int)nb;
+#ifdef APM_MEASURE
+    if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
+#endif
+    void *kargs[] = {&args};
+    return hipLaunchKernel((const void *)apm_sieve2_kernel, dim3((unsigned)(nb + a.n_tail)), dim3(APM_SIEVE2_BLOCK), kargs, lds, s);
+}
+
+// ---------------------------------------------------------------------------
+// VERIFY
+// ---------------------------------------------------------------------------
+// text of the shard behind a bounds-checked buffer resource: bytes at or beyond avail_pad (and "negative"
+// positions, which wrap to huge offsets) read as zero, for every path alike
+struct ApmBufText {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t off; // window start (relative position)
+    __device__ __forceinline__ bool can16(int) const { return true; }
+    __device__ __forceinline__ void load16(uint32_t (&T)[4]) const {
+        const uint32_t a0 = off & ~3u, sh = off & 3u;
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a0, 0, 0);
+        const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(a0 + 16u), 0, 0);
+        T[0] = __builtin_amdgcn_alignbyte(lo.y, lo.x, sh);
+        T[1] = __builtin_amdgcn_alignbyte(lo.z, lo.y, sh);
+        T[2] = __builtin_amdgcn_alignbyte(lo.w, lo.z, sh);
+        T[3] = __builtin_amdgcn_alignbyte(hi, lo.w, sh);
+    }
+    __device__ __forceinline__ int byte(int x) const { return (int)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)(off + (uint32_t)x), 0, 0); }
+};
+
+__host__ __device__ constexpr int apm_verify_scap(int band) { return ((64 + 2 * band) / (2 * band + 1) + 63 + 7) & ~7; }
+
+template <int BAND>
+__global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (*a.cand_n > a.cand_cap) return; // the list overflowed: the guarded fallback launches scan instead
+    constexpr int NSH = 2 * BAND + 1;
+    constexpr bool PAIRS = BAND >= 1;
+    constexpr uint32_t FLUSH_AT = (64 + NSH - 1) / NSH; // the DP pass runs once it fills a wave: (survivor, shift) items
+    constexpr int SCAP = apm_verify_scap(BAND);         // capacity of a wave's survivor list: FLUSH_AT - 1 + one round of 64
+    uint8_t *s_img = smem;
+    const uint32_t *s_bmp = reinterpret_cast<const uint32_t *>(s_img);
+    const uint16_t *s_prefix = reinterpret_cast<const uint16_t *>(s_img + a.o_prefix);
+    const uint16_t *s_r2s = reinterpret_cast<const uint16_t *>(s_img + a.o_r2s);
+    const uint16_t *s_slots = reinterpret_cast<const uint16_t *>(s_img + a.o_slots);
+    const uint32_t *s_kext = reinterpret_cast<const uint32_t *>(s_img + a.o_kext);
+    const uint8_t *s_pat = s_img + a.o_pat;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_img + a.image_len);
+    uint2 *s_surv = reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + wv * SCAP; // this wave's survivors {position, kid}
+    uint32_t *s_rc = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + (APM_BLOCK / 64) * SCAP); // [SHARDS] candidates in list region s
+    uint32_t *s_pre = s_rc + APM_CAND_SHARDS;                                                                                     // [SHARDS + 1] 64-candidate batches before region s
+
+    for (int i = tid; i < (a.image_len >> 4); i += APM_BLOCK) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
+    static_assert(APM_CAND_SHARDS == APM_BLOCK, "one thread per list region below");
+    s_rc[tid] = (uint32_t)a.shard_cnt[16 * tid]; // (<= shard_cap < 2^32: no overflow happened)
+    __syncthreads();
+    {
+        uint32_t before = 0;
+        for (int i = 0; i < tid; ++i) before += (s_rc[i] + 63u) >> 6;
+        s_pre[tid] = before;
+        if (tid == APM_CAND_SHARDS - 1) s_pre[APM_CAND_SHARDS] = before + ((s_rc[tid] + 63u) >> 6);
+    }
+    __syncthreads(); // the last workgroup barrier before the final count flush
+
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
+    const uint32_t avail = (uint32_t)a.avail;
+    const uint32_t cs = (uint32_t)a.code_shift;
+    const int n_pieces = a.k + 1;
+
+    // six dwords of text from the 4-byte aligned position a0: bytes [a0, a0 + 24)
+    struct Win { uint32_t w[6]; };
+    auto load_win = [&](uint32_t a0, Win &o) __attribute__((always_inline)) {
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a0, 0, 0);
+        const v2u32 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(a0 + 16u), 0, 0);
+        o.w[0] = lo.x; o.w[1] = lo.y; o.w[2] = lo.z; o.w[3] = lo.w; o.w[4] = hi.x; o.w[5] = hi.y;
+    };
+    auto gbyte = [&](uint32_t pos) __attribute__((always_inline)) { // (slow paths only)
+        return (int)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)pos, 0, 0);
+    };
+
+    // ---- the nomination predicate: key `kid` (one pigeonhole piece) at text position s --------------------
+    // piece intact at s, entirely inside the valid text, and (k >= 2) its partner of the pair pre-check within one
+    // edit (see apm_kernels.hip, "hierarchical verification").  `win` = the six text dwords at s & ~3.
+    // ONE definition for the candidates of the list and for the dedup's "earlier nominator" test.
+    auto stage1 = [&](uint32_t kid, uint32_t s, const Win &win) __attribute__((always_inline)) -> bool {
+        typedef unsigned long long u64;
+        const uint32_t kx = s_kext[kid];
+        const int at = (int)(kx & 0xffffu), len = (int)((kx >> 16) & 0xffu), n = (int)((kx >> 24) & 31u), side = (int)(kx >> 29);
+        if ((u64)s + (u64)len > (u64)avail) return false;
+        const uint32_t sh = s & 3u;
+        uint32_t A[4], B[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A[i] = __builtin_amdgcn_alignbyte(win.w[i + 1], win.w[i], sh); // text bytes [s, s+16)
+        apm_lds_dwords<4>(s_pat, at, B);
+        const u64 ml = len >= 8 ? ~0ull : ((1ull << (8 * len)) - 1ull);
+        const u64 mh = len <= 8 ? 0ull : (len >= 16 ? ~0ull : ((1ull << (8 * (len - 8))) - 1ull));
+        const u64 dl = (((u64)(A[1] ^ B[1]) << 32) | (A[0] ^ B[0])) & ml, dh = (((u64)(A[3] ^ B[3]) << 32) | (A[2] ^ B[2])) & mh;
+        if ((dl | dh) != 0ull) return false; // the piece is not intact
+        for (int x = 16; x < len; ++x)       // (pieces beyond 16 bytes: patterns with long pieces in this class)
+            if (gbyte(s + (uint32_t)x) != (int)s_pat[at + x]) return false;
+        if (!PAIRS || side == 0) return true; // no pre-check (k <= 1) / unpaired last piece (even k)
+        if (n == 31) { // partner longer than 16 bytes: byte loops (definition of the core, apm_ext_fwd / apm_ext_bwd)
+            const uint32_t ki = a.kinfo[kid];
+            const int kpat = (int)(ki & 0xfffu), q = (int)((ki >> 21) & 7u), p = q ^ 1;
+            const uint2 pinf = a.pinfo[kpat];
+            const int poff = (int)(pinf.x & 0xffffu), m = (int)(pinf.x >> 16), aux = (int)pinf.y;
+            const int ap = (int)a.poff[aux + p], ap1 = (p + 1 < n_pieces) ? (int)a.poff[aux + p + 1] : m, nn = ap1 - ap;
+            auto T = [&](int i) { return p > q ? gbyte(s + (uint32_t)len + (uint32_t)i) : gbyte(s - 1u - (uint32_t)i); };      // text, read away from the piece
+            auto P = [&](int i) { return p > q ? (int)s_pat[poff + ap + i] : (int)s_pat[poff + ap1 - 1 - i]; };                // partner, same direction
+            int i = 0;
+            while (i < nn && T(i) == P(i)) ++i;
+            if (i >= nn - 1) return true;
+            bool ok = true;
+            for (int j = i + 1; j < nn && ok; ++j) ok = T(j) == P(j);
+            if (ok) return true;
+            ok = true;
+            for (int j = i + 1; j < nn && ok; ++j) ok = T(j - 1) == P(j);
+            if (ok) return true;
+            ok = true;
+            for (int j = i; j < nn && ok; ++j) ok = T(j + 1) == P(j);
+            return ok;
+        }
+        uint32_t P[4], T[5];
+        Win tw;
+        if (side == 1) { // partner behind the piece: text read forward from the end of the piece
+            const uint32_t tp = s + (uint32_t)len;
+            load_win(tp & ~3u, tw);
+            apm_lds_dwords<4>(s_pat, at + len, P);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) T[i] = __builtin_amdgcn_alignbyte(tw.w[i + 1], tw.w[i], tp & 3u);
+        } else { // partner in front of it: both strings byte-reversed, text = the 20 bytes in front of s
+            uint32_t Q[4], Wd[5];
+            apm_lds_dwords<4>(s_pat, at - 16, Q);
+            if (s >= 20u) {
+                const uint32_t tp = s - 20u;
+                load_win(tp & ~3u, tw);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Wd[i] = __builtin_amdgcn_alignbyte(tw.w[i + 1], tw.w[i], tp & 3u);
+            } else { // the first 20 positions of the shard: bytes in front of text[0] do not exist and read as zero
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Wd[i] = 0u;
+                for (int i = 20 - (int)s; i < 20; ++i) {
+                    const uint32_t b = (uint32_t)gbyte(s - 20u + (uint32_t)i);
+#pragma unroll
+                    for (int d = 0; d < 5; ++d)
+                        if ((i >> 2) == d) Wd[d] |= b << (8 * (i & 3));
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < 4; ++z) P[z] = apm_bswap(Q[3 - z]);
+#pragma unroll
+            for (int z = 0; z < 5; ++z) T[z] = apm_bswap(Wd[4 - z]);
+        }
+        return apm_ext1_core16(P, T, n);
+    };
+
+    // ---- banded DP of the window a nomination implies under shift dl + stateless dedup; bumps s_cnt ----
+    auto dp_item = [&](uint32_t kid, uint32_t s, int dl) __attribute__((always_inline)) {
+        const uint32_t ki = a.kinfo[kid];
+        const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kpiece = (int)((ki >> 21) & 7u);
+        const uint2 pinf = a.pinfo[kpat];
+        const int poff = (int)(pinf.x & 0xffffu), m = (int)(pinf.x >> 16), aux = (int)pinf.y;
+        const int64_t je_p = min(a.je, a.nrel - m + 1);
+        const int64_t j = (int64_t)s - koff - dl; // candidate window start
+        if (j < a.jb || j >= je_p) return;
+        if (!apm_banded_verify<BAND>(ApmBufText{rs, (uint32_t)j}, s_pat, poff, m, a.k)) return;
+        // count the window once: only from its first true (piece, shift) nominator
+        for (int qq = 0; qq <= kpiece; ++qq) {
+            const int aq = (int)a.poff[aux + qq];
+            for (int dd = -BAND; dd <= BAND; ++dd) {
+                if (qq == kpiece && dd >= dl) break;
+                const int64_t o = j + aq + dd; // piece start under shift dd
+                if (o < 0) continue;
+                Win w2;
+                load_win((uint32_t)o & ~3u, w2);
+                if (stage1((uint32_t)(kpat * n_pieces + qq), (uint32_t)o, w2)) return;
+            }
+        }
+        atomicAdd(&s_cnt[kpat], 1u);
+    };
+
+    // ---- batches of 64 candidates per wave.  One loop, one stage-1 site, one DP site: each trip either runs the
+    // DP pass over the wave's survivor list, or moves to the next (batch, parity), or evaluates the predicate once
+    // for every lane that still has a key to try at its position. ----
+    uint32_t n_surv = 0; // wave-uniform
+    // the batches of all regions, in region order, are dealt to the waves in equal contiguous runs
+    const uint32_t n_batches = s_pre[APM_CAND_SHARDS];
+    const uint32_t n_waves = (uint32_t)a.n_blocks * (APM_BLOCK / 64), my_wave = blockIdx.x * (APM_BLOCK / 64) + (uint32_t)wv;
+    uint32_t bi = (uint32_t)(((unsigned long long)n_batches * my_wave) / n_waves);
+    const uint32_t b_end = (uint32_t)(((unsigned long long)n_batches * (my_wave + 1u)) / n_waves);
+    uint32_t sh = 0; // region of batch bi: the last one with s_pre[sh] <= bi
+    for (uint32_t step = APM_CAND_SHARDS / 2; step; step >>= 1)
+        if (s_pre[sh + step] <= bi) sh += step;
+    // the candidates of the wave's batches, in order; false once the run is exhausted
+    auto next_cand = [&](uint32_t &q, bool &hv) __attribute__((always_inline)) -> bool {
+        q = 0;
+        hv = false;
+        if (bi >= b_end) return false;
+        while (s_pre[sh + 1] <= bi) ++sh; // (bi < n_batches = s_pre[SHARDS]: ends at a non-empty region)
+        const uint32_t in_region = (bi - s_pre[sh]) * 64u + (uint32_t)lane;
+        hv = in_region < s_rc[sh];
+        if (hv) q = a.cand[(size_t)sh * (size_t)a.shard_cap + in_region];
+        ++bi;
+        return true;
+    };
+    // two batches ahead: the list entries of batch b+2 and the text windows of batch b+1 are in flight while batch b
+    // is worked on (vmcnt counts in order: the loads of the pre-check queue behind them and wait for no more)
+    bool done = false, active = false, have = false;
+    uint32_t p = 0, str = 0, s = 0, pend = 0;
+    uint32_t cur = 0, nxt = 0; // current key id | 0x8000 when it is the last of its list; index of the next slot
+    Win win, win_n;
+    uint32_t q_n, q_nn;
+    bool have_n, have_nn;
+    bool ex_n = next_cand(q_n, have_n);
+    load_win((q_n << 1) & ~3u, win_n);
+    bool ex_nn = next_cand(q_nn, have_nn);
+    for (;;) {
+        if (n_surv >= FLUSH_AT || (done && n_surv)) {
+            for (uint32_t wi = (uint32_t)lane; wi < n_surv * NSH; wi += 64) {
+                const uint2 e = s_surv[wi / NSH];
+                dp_item(e.y, e.x, (int)(wi % NSH) - BAND);
+            }
+            n_surv = 0;
+        }
+        if (done) break;
+        // a lane without a key in hand takes up the next of its (at most two) hit positions: key list by rank
+        if (!active && pend) {
+            const uint32_t par = (pend & 1u) ? 0u : 1u;
+            pend &= pend - 1u;
+            const uint32_t x = (str >> (2u * par)) & 0xffffu, bit = x >> 11;
+            const uint32_t word = s_bmp[x & 2047u];
+            const uint32_t e = s_r2s[(uint32_t)s_prefix[x & 2047u] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))];
+            s = p + par;
+            if (e & 0x8000u) cur = e;
+            else { cur = s_slots[e]; nxt = e + 1u; }
+            active = true;
+        }
+        if (!__builtin_amdgcn_ballot_w64(active)) { // this batch is exhausted: rotate the pipeline
+            if (!ex_n) { done = true; continue; }
+            p = q_n << 1; // even relative position
+            have = have_n;
+            win = win_n;
+            ex_n = ex_nn;
+            q_n = q_nn;
+            have_n = have_nn;
+            load_win((q_n << 1) & ~3u, win_n);
+            ex_nn = next_cand(q_nn, have_nn);
+            // code words of the 8-byte windows at p and p + 1 (16 bits each) out of the 12 bytes from p on
+            str = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t b4 = __builtin_amdgcn_alignbyte(win.w[i + 1], win.w[i], p & 3u);
+                str |= apm_udot4((b4 >> cs) & 0x03030303u, 0x40100401u) << (8 * i);
+            }
+            const uint32_t x0 = str & 0xffffu, x1 = (str >> 2) & 0xffffu;
+            pend = have ? (((s_bmp[x0 & 2047u] >> (x0 >> 11)) & 1u) | (((s_bmp[x1 & 2047u] >> (x1 >> 11)) & 1u) << 1)) : 0u;
+#ifdef APM_MEASURE
+            if (APM_SKIP(a, 8)) pend = 0;
+#endif
+            continue;
+        }
+        bool ok = false;
+        if (active) ok = stage1(cur & 0x7fffu, s, win);
+#ifdef APM_MEASURE
+        if (APM_SKIP(a, 16)) ok = false;
+#endif
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+        if (mask) { // survivors -> the wave's list (ballot + mbcnt, no atomics); at most FLUSH_AT - 1 + 64 entries
+            const uint32_t idx = n_surv + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (ok) s_surv[idx] = make_uint2(s, cur & 0x7fffu);
+            n_surv += (uint32_t)__builtin_popcountll(mask);
+        }
+        if (active) {
+            if (cur & 0x8000u) active = false;
+            else cur = s_slots[nxt++];
+        }
+    }
+
+    __syncthreads();
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
+        const uint32_t cnt = s_cnt[i];
+        if (cnt) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)cnt);
+    }
+}
+
+size_t apm_verify_lds_bytes(const ApmVerifyArgs &a) {
+    return (size_t)a.image_len + (size_t)((a.n_pats + 3) & ~3) * 4 + (size_t)(APM_BLOCK / 64) * (size_t)apm_verify_scap(a.band) * 8 +
+           (size_t)(2 * APM_CAND_SHARDS + 4) * 4 + 16; // image + counts + 4 survivor lists + region tables
+}
+
+static const void *apm_verify_fn(int band) {
+    switch (band) {
+    case 0: return (const void *)apm_verify_kernel<0>;
+    case 1: return (const void *)apm_verify_kernel<1>;
+    case 2: return (const void *)apm_verify_kernel<2>;
+    case 3: return (const void *)apm_verify_kernel<3>;
+    default: return nullptr;
+    }
+}
+
+int apm_verify_blocks_per_cu(const ApmVerifyArgs &a) {
+    int per_cu = 0;
+    const void *fn = apm_verify_fn(a.band);
+    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, APM_BLOCK, apm_verify_lds_bytes(a)) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    return per_cu > 8 ? 8 : per_cu;
+}
+
+hipError_t apm_launch_verify(const ApmVerifyArgs &a, int max_blocks, hipStream_t s) {
+    if (a.n_pats <= 0) return hipSuccess;
+    const void *fn = apm_verify_fn(a.band);
+    if (!fn) return hipErrorInvalidValue;
+    ApmVerifyArgs args = a;
+    args.n_blocks = max_blocks < 1 ? 1 : max_blocks; // (list length unknown on the host: a persistent grid strides over it)
+#ifdef APM_MEASURE
+    if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
+#endif
+    void *kargs[] = {&args};
+    return hipLaunchKernel(fn, dim3((unsigned)args.n_blocks), dim3(APM_BLOCK), kargs, apm_verify_lds_bytes(a), s);
+}

@@ -91,22 +91,23 @@ def test_no_kernel_spills_to_scratch():
     """csrc/apm_kernels.resources.txt (written by the Makefile from the compiler's resource-usage
     remarks): a spill reload inside a streaming loop is a vector-memory op that drains every prefetch
     queued behind it (vmcnt counts in order) -- it cost 10 % on the headline kernel once."""
-    path = os.path.join(H.PKG_DIR, "csrc", "apm_kernels.resources.txt")
-    if not os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(H.PKG_DIR, "csrc", "*.resources.txt")))
+    if len(paths) < 2:
         pytest.skip("library was not built by the Makefile in this checkout")
     name, seen = None, 0
-    for line in open(path):
+    for line in (l for p in paths for l in open(p)):
         if line.startswith("Function Name:"):
             name = line.split(":", 1)[1].strip()
         elif line.startswith("ScratchSize"):
             seen += 1
             spilled = int(line.rsplit(":", 1)[1])
-            # Streaming kernels (stream, sieve, full-DP scans) must not spill at all.  The LDS-tile kernel with a
+            # Streaming kernels (stream, sieve, verify, full-DP scans) must not spill at all.  The LDS-tile kernel with a
             # band is verification bound: for its per-position variants a few spilled dwords measured faster than
             # the next lower occupancy (cfg3: 2.51 vs 2.69 ms), so a small budget is tolerated there and only there.
             tile_banded = "apm_filter_kernel" in name and "ILi0E" not in name
             assert spilled <= (48 if tile_banded else 0), "%s spills %d bytes to scratch" % (name, spilled)
-        elif line.startswith("LDS Size") and ("apm_filter_kernel" in name or "apm_stream_kernel" in name):
+        elif line.startswith("LDS Size") and ("apm_filter_kernel" in name or "apm_stream_kernel" in name or "apm_sieve2_kernel" in name):
             # their key bitmap is addressed as a compile-time LDS constant: dynamic LDS must start at 0
             assert int(line.rsplit(":", 1)[1]) == 0, "%s owns static LDS" % name
     assert seen >= 40
