@@ -136,4 +136,115 @@ APM_HD bool apm_ext1_core16(const uint32_t (&p)[4], const uint32_t (&t)[5], int 
     return (((Pl ^ Tul) & nl & el) | ((Ph ^ Tuh) & nh & eh)) == 0ull; // one extra text byte before pattern byte i
 }
 
+/* ---------------------------------------------------------------------------
+ * Host side of the presence bitmaps (plan builder in apm_runtime.hip; tests/host_core_test.cpp checks the
+ * constructive enumeration against the brute-force definition).
+ *
+ * A nomination UNIT of a pattern is an exact part pat[off, off+len) followed (side 1) or preceded (side 2) by a
+ * partner pat[poff, poff+plen) that must match the adjoining text within ONE edit, anchored at the exact part and
+ * free at its far end (apm_ext1_core16 / apm_ext_fwd semantics); side 0 = no partner.  len may be 0 with side 1:
+ * the whole unit is then "partner within one edit from the unit's text position on" (a pair of short pieces).
+ * apm_enum_unit_windows calls fn(x) for every 16-bit word x of 2-bit codes (byte z of the window in bits 2z..,
+ * code = (byte >> shift) & 3) that the 8 text bytes at the unit's position may show when the unit's predicate holds:
+ * a superset is fine (the bitmap is a filter), a missing word would lose matches.
+ * ------------------------------------------------------------------------- */
+#if 1 /* host functions (parsed in both passes of a .hip unit) */
+struct ApmUnit {
+    int off, len;   /* exact part */
+    int poff, plen; /* partner (side != 0) */
+    int side;       /* 0 none, 1 partner behind the exact part, 2 in front of it */
+};
+
+/* can the text codes t[0..vis) (the first vis text bytes behind the exact part) still belong to a text that matches
+   the partner codes c[0..n) within one edit?  (bytes beyond vis are unknown = wildcards) */
+inline bool apm_ext1_visible_ok(const uint8_t *c, int n, const uint8_t *t, int vis) {
+    int i = 0;
+    while (i < n && i < vis && t[i] == c[i]) ++i;
+    if (i >= vis || i >= n - 1) return true;
+    bool ok = true; /* substitution at i */
+    for (int j = i + 1; j < n && j < vis && ok; ++j) ok = t[j] == c[j];
+    if (ok) return true;
+    ok = true; /* pattern byte i has no text counterpart */
+    for (int j = i + 1; j < n && j - 1 < vis && ok; ++j) ok = t[j - 1] == c[j];
+    if (ok) return true;
+    ok = true; /* one extra text byte before pattern byte i */
+    for (int j = i; j < n && j + 1 < vis && ok; ++j) ok = t[j + 1] == c[j];
+    return ok;
+}
+
+/* definition: every continuation of the visible exact part, filtered by apm_ext1_visible_ok */
+template <typename F>
+inline void apm_enum_unit_windows_bruteforce(const uint8_t *pat, const ApmUnit &u, int shift, F fn) {
+    const int vis = u.len < 8 ? u.len : 8, ext = 8 - vis;
+    uint32_t x = 0;
+    for (int z = 0; z < vis; ++z) x |= (uint32_t)((pat[u.off + z] >> shift) & 3) << (2 * z);
+    uint8_t c[64], t[8];
+    const int n = u.side == 1 ? (u.plen < 64 ? u.plen : 64) : 0;
+    for (int i = 0; i < n; ++i) c[i] = (uint8_t)((pat[u.poff + i] >> shift) & 3);
+    for (uint32_t p = 0; p < (1u << (2 * ext)); ++p) {
+        for (int j = 0; j < ext; ++j) t[j] = (uint8_t)((p >> (2 * j)) & 3u);
+        if (u.side != 1 || ext == 0 || apm_ext1_visible_ok(c, n, t, ext)) fn(x | (p << (2 * vis)));
+    }
+}
+
+/* the same set (or a superset), generated from the edit neighbourhood instead of filtered out of 4^ext words */
+template <typename F>
+inline void apm_enum_unit_windows(const uint8_t *pat, const ApmUnit &u, int shift, F fn) {
+    const int vis = u.len < 8 ? u.len : 8, ext = 8 - vis;
+    if (u.side != 1 || ext <= 4) { /* at most 256 continuations: the definition is cheap enough */
+        apm_enum_unit_windows_bruteforce(pat, u, shift, fn);
+        return;
+    }
+    uint32_t x = 0;
+    for (int z = 0; z < vis; ++z) x |= (uint32_t)((pat[u.off + z] >> shift) & 3) << (2 * z);
+    uint8_t c[64];
+    const int n = u.plen < 64 ? u.plen : 64;
+    for (int i = 0; i < n; ++i) c[i] = (uint8_t)((pat[u.poff + i] >> shift) & 3);
+    /* emit the words whose visible part is w[0..ext) with `wild` = bitmask of positions that may hold any code */
+    auto emit = [&](const uint8_t *w, uint32_t wild) {
+        int wp[8], nw = 0;
+        uint32_t base = 0;
+        for (int j = 0; j < ext; ++j) {
+            if ((wild >> j) & 1u) wp[nw++] = j;
+            else base |= (uint32_t)w[j] << (2 * j);
+        }
+        for (uint32_t q = 0; q < (1u << (2 * nw)); ++q) {
+            uint32_t v = base;
+            for (int z = 0; z < nw; ++z) v |= ((q >> (2 * z)) & 3u) << (2 * wp[z]);
+            fn(x | (v << (2 * vis)));
+        }
+    };
+    uint8_t w[8];
+    /* no edit inside the visible part / a substitution at i (any code there) */
+    for (int i = -1; i < ext && i < n; ++i) {
+        uint32_t wild = 0;
+        for (int j = 0; j < ext; ++j) {
+            if (j >= n || j == i) wild |= 1u << j;
+            else w[j] = c[j];
+        }
+        emit(w, wild);
+    }
+    /* pattern byte i has no text counterpart: text = c[0..i) c[i+1..] */
+    for (int i = 0; i < n && i <= ext; ++i) {
+        uint32_t wild = 0;
+        for (int j = 0; j < ext; ++j) {
+            const int src = j < i ? j : j + 1;
+            if (src >= n) wild |= 1u << j;
+            else w[j] = c[src];
+        }
+        emit(w, wild);
+    }
+    /* one extra text byte before pattern byte i: text = c[0..i) ? c[i..] */
+    for (int i = 0; i < n && i < ext; ++i) {
+        uint32_t wild = 0;
+        for (int j = 0; j < ext; ++j) {
+            const int src = j < i ? j : j - 1;
+            if (j == i || src >= n) wild |= 1u << j;
+            else w[j] = c[src];
+        }
+        emit(w, wild);
+    }
+}
+#endif /* host */
+
 #endif /* APM_CORE_H */

@@ -36,7 +36,24 @@ __device__ __forceinline__ void apm_lds_dwords(const uint8_t *base, int off, uin
 template <int BAND, typename Text>
 __device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t *pb, int poff, int m, int k) {
     const uint8_t *p = pb + poff;
-    if constexpr (BAND == 0) {
+    if constexpr (BAND == 0 && Text::kBlocks) {
+        // Hamming distance, 16 bytes per step: nonzero bytes of text ^ pattern counted with the carry trick
+        int mism = 0;
+        for (int xb = 0; xb < m; xb += 16) {
+            uint32_t Tb[4], Pb[4];
+            tx.load16_at(xb, Tb);
+            apm_lds_dwords<4>(pb, poff + xb, Pb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int valid = m - xb - 4 * i; // bytes of this dword inside the window
+                const uint32_t mask = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+                const uint32_t x = (Tb[i] ^ Pb[i]) & mask;
+                mism += __builtin_popcount((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u);
+            }
+            if (mism > k) return false;
+        }
+        return true;
+    } else if constexpr (BAND == 0) {
         int mism = 0;
         for (int x = 0; x < m; ++x) {
             mism += (tx.byte(x) != (int)p[x]) ? 1 : 0;
@@ -79,6 +96,40 @@ __device__ __forceinline__ bool apm_banded_verify(const Text &tx, const uint8_t 
                 if ((x & 3) == 0 && best > k) return false;
             }
             x0 = 17;
+            if constexpr (Text::kBlocks) {
+                // the remaining columns 16 at a time, text and pattern bytes fetched as dwords up front (a byte load
+                // per column from global memory would chain their latencies): block b covers columns xb .. xb+15,
+                // its pattern window starts at byte xb - 1 - BAND (cell (xb + xi, xb + xi + i - BAND) reads byte xi + i)
+                for (int xb = 17; xb <= m; xb += 16) {
+                    uint32_t Tb[4], Pb[6];
+                    tx.load16_at(xb - 1, Tb);
+                    apm_lds_dwords<6>(pb, poff + xb - 1 - BAND, Pb);
+#pragma unroll
+                    for (int xi = 0; xi < 16; ++xi) {
+                        const int x = xb + xi;
+                        const int tc = (int)((Tb[xi >> 2] >> (8 * (xi & 3))) & 0xffu);
+                        int up = INF, best = INF;
+                        if (x <= m) {
+#pragma unroll
+                            for (int i = 0; i < NB; ++i) {
+                                const int y = x + i - BAND; // >= 17 - BAND >= 1
+                                int nv = INF;
+                                if (y <= m) {
+                                    const int pc = (int)((Pb[(xi + i) >> 2] >> (8 * ((xi + i) & 3))) & 0xffu);
+                                    const int diag = e[i] + ((pc != tc) ? 1 : 0);
+                                    const int left = (i + 1 < NB) ? e[i + 1] + 1 : INF;
+                                    nv = apm_min3(diag, left, up + 1);
+                                }
+                                e[i] = nv;
+                                up = nv;
+                                best = min(best, nv);
+                            }
+                            if ((xi & 3) == 3 && best > k) return false;
+                        }
+                    }
+                }
+                return e[BAND] <= k;
+            }
         }
         for (int x = x0; x <= m; ++x) {
             const int tc = tx.byte(x - 1);

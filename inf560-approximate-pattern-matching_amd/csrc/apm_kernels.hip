@@ -495,6 +495,7 @@ __device__ __forceinline__ bool apm_key_equal(const uint8_t *tb, int toff, const
 struct ApmLdsText {
     const uint8_t *base; // 16-byte aligned LDS buffer
     int off;             // window start inside it
+    static constexpr bool kBlocks = false;
     __device__ __forceinline__ bool can16(int) const { return true; }
     __device__ __forceinline__ void load16(uint32_t (&T)[4]) const { apm_lds_dwords<4>(base, off, T); }
     __device__ __forceinline__ int byte(int x) const { return (int)base[off + x]; }
@@ -503,6 +504,7 @@ struct ApmGlobalText {
     const uint8_t *text; // 16-byte aligned
     int64_t off;         // window start (relative position)
     int64_t limit;       // bytes readable from text (avail_pad)
+    static constexpr bool kBlocks = false;
     __device__ __forceinline__ bool can16(int) const { return (off & ~(int64_t)3) + 20 <= limit; }
     __device__ __forceinline__ void load16(uint32_t (&T)[4]) const {
         const uint32_t *a = reinterpret_cast<const uint32_t *>(text + (off & ~(int64_t)3));

@@ -82,11 +82,11 @@ struct TiledLaunch {       // host description of one tiled scan launch
 };
 
 struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns and its LDS image (apm_sieve.hip)
-    std::vector<ApmPatDesc> descs;    // m, index, byte_off (into bytes), aux_off (into piece_off)
+    std::vector<ApmPatDesc> descs;    // m, index, byte_off (into bytes), aux_off = first key, w = number of keys
     std::vector<uint8_t> bytes;       // raw pattern bytes
-    std::vector<uint16_t> piece_off;  // piece offsets, per pattern contiguous
-    std::vector<uint32_t> kinfo;      // per key (id = pattern slot * (k+1) + piece): pat | off << 12 | piece << 21
-    std::vector<uint32_t> pinfo;      // per pattern: {byte_off | m << 16, first piece_off index}
+    std::vector<uint32_t> kinfo;      // per key = nomination unit: pat | off << 12 | unit index << 21 (a pattern's units are consecutive keys)
+    std::vector<uint32_t> kpart;      // per key: partner offset inside the pattern | partner length << 16
+    std::vector<uint32_t> pinfo;      // per pattern: {byte_off | m << 16, id of its first key}
     std::vector<uint8_t> image;       // bitmap16 | prefix | r2s | slots | kext | pattern bytes
     int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0;
     int m_max = 0, m_min = 0;
@@ -107,7 +107,7 @@ struct DevVerify {
     uint8_t *d_image = nullptr;
     uint32_t *d_kinfo = nullptr;
     uint32_t *d_pinfo = nullptr;
-    uint16_t *d_poff = nullptr;
+    uint32_t *d_kpart = nullptr;
 };
 
 struct GenericGroup {      // patterns scanned by the generic kernel, one launch (grid.y = pattern)
@@ -296,7 +296,7 @@ void free_device_plan(DeviceState &ds) {
         if (v.d_image) hipFree(v.d_image);
         if (v.d_kinfo) hipFree(v.d_kinfo);
         if (v.d_pinfo) hipFree(v.d_pinfo);
-        if (v.d_poff) hipFree(v.d_poff);
+        if (v.d_kpart) hipFree(v.d_kpart);
     }
     ds.verify.clear();
 }
@@ -387,8 +387,37 @@ int build_sieve_plan(apm_ctx *ctx) {
     }
     S.bitmap.assign(8192, 0u);
     std::vector<uint8_t> seen16(8192, 0); // union of the launches' 16-bit code words (byte x & 8191, bit x >> 13)
+    // nomination units of a pattern (apm_core.h, ApmUnit): per pair of pigeonhole pieces (A, B) either the two
+    // piece units "A intact + B within one edit behind it" and "B intact + A within one edit in front of it", or --
+    // when both pieces are short -- ONE pair unit "A+B within one edit"; whichever shows fewer 8-byte code words to
+    // the sieve.  The unpaired last piece (even k) is a unit without partner; without the pair pre-check (k <= 1)
+    // every piece is.  Every window with <= k edits has a unit whose predicate holds at the right text position.
+    auto count_words = [&](const uint8_t *pat, const std::vector<ApmUnit> &us) {
+        std::vector<uint32_t> w;
+        for (const ApmUnit &u : us) apm_enum_unit_windows(pat, u, S.code_shift, [&](uint32_t x) { w.push_back(x); });
+        std::sort(w.begin(), w.end());
+        return (size_t)(std::unique(w.begin(), w.end()) - w.begin());
+    };
+    auto units_of = [&](const uint8_t *pat, int m) {
+        std::vector<ApmUnit> us;
+        auto a = [&](int q) { return q >= pieces ? m : (int)((int64_t)q * m / pieces); };
+        for (int q = 0; q < pieces; q += pairs ? 2 : 1) {
+            const int lenA = a(q + 1) - a(q);
+            if (!pairs || q + 1 >= pieces) {
+                us.push_back(ApmUnit{a(q), lenA, 0, 0, 0});
+                continue;
+            }
+            const int lenB = a(q + 2) - a(q + 1);
+            const std::vector<ApmUnit> by_piece = {ApmUnit{a(q), lenA, a(q + 1), lenB, 1}, ApmUnit{a(q + 1), lenB, a(q), lenA, 2}};
+            const std::vector<ApmUnit> by_pair = {ApmUnit{a(q), 0, a(q), lenA + lenB, 1}};
+            if (lenA + lenB <= 16 && lenA < 8 && lenB < 8 && count_words(pat, by_pair) < count_words(pat, by_piece)) us.push_back(by_pair[0]);
+            else us.insert(us.end(), by_piece.begin(), by_piece.end());
+        }
+        return us;
+    };
     for (size_t pos = 0; pos < idx.size();) {
         VerifyLaunch V;
+        std::vector<ApmUnit> units; // per key, offsets relative to the pattern
         for (; pos < idx.size(); ++pos) {
             const PatternInfo &pi = ctx->pats[idx[pos]];
             if (!V.descs.empty() && (V.bytes.size() + (size_t)pi.m > 24576 || V.kinfo.size() + (size_t)pieces > 8192 || V.descs.size() >= 4096))
@@ -397,13 +426,14 @@ int build_sieve_plan(apm_ctx *ctx) {
             d.m = (uint32_t)pi.m;
             d.index = (uint32_t)idx[pos];
             d.byte_off = (uint32_t)V.bytes.size();
-            d.aux_off = (uint32_t)V.piece_off.size();
-            d.w = (uint32_t)pieces;
+            d.aux_off = (uint32_t)V.kinfo.size(); // first key
             V.bytes.insert(V.bytes.end(), pi.bytes.begin(), pi.bytes.end());
-            for (int q = 0; q < pieces; ++q) {
-                const int aq = (int)((int64_t)q * pi.m / pieces);
-                V.piece_off.push_back((uint16_t)aq);
-                V.kinfo.push_back((uint32_t)V.descs.size() | ((uint32_t)aq << 12) | ((uint32_t)q << 21));
+            const std::vector<ApmUnit> us = units_of(reinterpret_cast<const uint8_t *>(pi.bytes.data()), pi.m);
+            d.w = (uint32_t)us.size();
+            for (size_t ui = 0; ui < us.size(); ++ui) {
+                V.kinfo.push_back((uint32_t)V.descs.size() | ((uint32_t)us[ui].off << 12) | ((uint32_t)ui << 21));
+                V.kpart.push_back((uint32_t)us[ui].poff | ((uint32_t)us[ui].plen << 16));
+                units.push_back(us[ui]);
             }
             V.pinfo.push_back(d.byte_off | (d.m << 16));
             V.pinfo.push_back(d.aux_off);
@@ -416,25 +446,15 @@ int build_sieve_plan(apm_ctx *ctx) {
         auto rank_key = [](uint32_t x) { return ((x & 2047u) << 5) | (x >> 11); };
         std::vector<uint64_t> wk;
         std::vector<uint32_t> kext;
-        for (size_t ps = 0; ps < V.descs.size(); ++ps) {
-            const ApmPatDesc &dd = V.descs[ps];
-            const uint8_t *pat = V.bytes.data() + dd.byte_off;
-            const uint16_t *poffs = V.piece_off.data() + dd.aux_off;
-            auto piece_begin = [&](int q) { return q >= pieces ? (int)dd.m : (int)poffs[q]; };
-            for (int q = 0; q < pieces; ++q) {
-                const uint32_t kid = (uint32_t)(ps * (size_t)pieces + (size_t)q);
-                const int len = piece_begin(q + 1) - piece_begin(q);
-                enum_key_windows(pat, (int)dd.m, poffs, pieces, q, len, S.code_shift, pairs,
-                                 [&](uint32_t xx) { wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | kid); });
-                const int pq = q ^ 1;
-                uint32_t side = 0, plen = 0;
-                if (pairs && pq < pieces) {
-                    side = pq > q ? 1u : 2u;
-                    plen = (uint32_t)(piece_begin(pq + 1) - piece_begin(pq));
-                }
-                kext.push_back((uint32_t)(dd.byte_off + (uint32_t)piece_begin(q)) | (std::min<uint32_t>((uint32_t)len, 255u) << 16) |
-                               ((plen > 16 ? 31u : plen) << 24) | (side << 29));
-            }
+        for (size_t kid = 0; kid < units.size(); ++kid) {
+            const ApmUnit &u = units[kid];
+            const ApmPatDesc &dd = V.descs[V.kinfo[kid] & 0xfffu];
+            apm_enum_unit_windows(V.bytes.data() + dd.byte_off, u, S.code_shift,
+                                  [&](uint32_t xx) { wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | (uint64_t)kid); });
+            // packed pre-check record: byte offset of the exact part in the pattern pool | its length << 16 |
+            // partner length << 24 (31 = beyond 16) | side << 29
+            kext.push_back((uint32_t)(dd.byte_off + (uint32_t)u.off) | (std::min<uint32_t>((uint32_t)u.len, 255u) << 16) |
+                           ((u.plen > 16 ? 31u : (uint32_t)u.plen) << 24) | ((uint32_t)u.side << 29));
         }
         std::sort(wk.begin(), wk.end());
         wk.erase(std::unique(wk.begin(), wk.end()), wk.end());
@@ -847,7 +867,7 @@ int build_plan(apm_ctx *ctx) {
                 if ((rc = upload_vec(ctx, &ds.verify[v].d_image, V.image))) return rc;
                 if ((rc = upload_vec(ctx, &ds.verify[v].d_kinfo, V.kinfo))) return rc;
                 if ((rc = upload_vec(ctx, &ds.verify[v].d_pinfo, V.pinfo))) return rc;
-                if ((rc = upload_vec(ctx, &ds.verify[v].d_poff, V.piece_off))) return rc;
+                if ((rc = upload_vec(ctx, &ds.verify[v].d_kpart, V.kpart))) return rc;
             }
         }
         ds.tiled.resize(ctx->tiled.size());
@@ -1024,7 +1044,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 va.o_pat = V.o_pat;
                 va.kinfo = ds.verify[v].d_kinfo;
                 va.pinfo = reinterpret_cast<const uint2 *>(ds.verify[v].d_pinfo);
-                va.poff = ds.verify[v].d_poff;
+                va.kpart = ds.verify[v].d_kpart;
                 va.pats = ds.verify[v].d_descs;
                 va.counts = d_counts;
                 va.n_pats = (int)V.descs.size();
@@ -1037,6 +1057,9 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 va.shard_cap = sv.shard_cap;
                 va.cand_n = sv.cand_n;
                 va.cand_cap = sv.cand_cap;
+#ifdef APM_MEASURE
+                va.stats = ds.d_cand + 2;
+#endif
                 if (!V.blocks_per_cu) V.blocks_per_cu = apm_verify_blocks_per_cu(va);
                 HIP_TRY(ctx, apm_launch_verify(va, ds.n_cu * V.blocks_per_cu, ds.stream));
                 { const int nrc = note_launch(ctx, ds, "verify"); if (nrc) return nrc; }
@@ -1798,13 +1821,19 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }
     if (n == "verify_image_bytes") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].image.size(); return APM_OK; }
     if (n == "verify_blocks_per_cu") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].blocks_per_cu; return APM_OK; }
-    if (n == "sieve_candidates" || n == "sieve_overflow") { // of the last call (synchronises with the stream)
+    if (n == "sieve_candidates" || n == "sieve_overflow" || n.rfind("verify_", 0) == 0) { // of the last call (synchronises with the stream)
         if (!ds.d_cand) { *value = 0; return APM_OK; }
         HIP_TRY(ctx, hipSetDevice(ds.dev));
         HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
         std::vector<unsigned long long> h(8 + 16 * APM_CAND_SHARDS);
         HIP_TRY(ctx, hipMemcpy(h.data(), ds.d_cand, h.size() * 8, hipMemcpyDeviceToHost));
         if (n == "sieve_overflow") { *value = h[0] > ds.cand_cap ? 1 : 0; return APM_OK; }
+#ifdef APM_MEASURE
+        if (n == "verify_prechecks") { *value = (double)h[2]; return APM_OK; }
+        if (n == "verify_survivors") { *value = (double)h[3]; return APM_OK; }
+        if (n == "verify_dp_items") { *value = (double)h[4]; return APM_OK; }
+        if (n == "verify_counted") { *value = (double)h[5]; return APM_OK; }
+#endif
         double sum = 0;
         for (int i = 0; i < APM_CAND_SHARDS; ++i) sum += (double)h[8 + 16 * (size_t)i];
         *value = sum;

@@ -53,9 +53,10 @@ struct ApmVerifyArgs {
     const uint4 *image;
     int image_len, o_prefix, o_r2s, o_slots, o_kext, o_pat;
     /* the records only the (rare) banded DP needs stay in global memory */
-    const uint32_t *kinfo;      /* per key: pat | off << 12 | piece << 21 */
-    const uint2 *pinfo;         /* per pattern: {byte_off | m << 16, first piece-offset index}; key id = pat * (k+1) + piece */
-    const uint16_t *poff;       /* piece offsets */
+    const uint32_t *kinfo;      /* per key = nomination unit: pat | off << 12 | unit index inside the pattern << 21; off = offset of
+                                   the unit's text position inside the window (window start = position - off - shift) */
+    const uint2 *pinfo;         /* per pattern: {byte_off | m << 16, id of its first key}; a pattern's units are consecutive keys */
+    const uint32_t *kpart;      /* per key: partner offset inside the pattern | partner length << 16 (partners beyond 16 bytes only) */
     const ApmPatDesc *pats;     /* index = counts[] slot */
     unsigned long long *counts;
     int n_pats, nk, k, band, code_shift;
@@ -67,6 +68,7 @@ struct ApmVerifyArgs {
     int n_blocks;               /* set by the launcher */
 #ifdef APM_MEASURE
     int skip_mask;
+    unsigned long long *stats;  /* [0] pre-check evaluations, [1] survivors, [2] DP items run, [3] windows counted */
 #endif
 };
 

@@ -156,9 +156,11 @@ hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
 struct ApmBufText {
     __amdgpu_buffer_rsrc_t rs;
     uint32_t off; // window start (relative position)
+    static constexpr bool kBlocks = true; // the DP fetches its columns 16 at a time (apm_banded_verify)
     __device__ __forceinline__ bool can16(int) const { return true; }
-    __device__ __forceinline__ void load16(uint32_t (&T)[4]) const {
-        const uint32_t a0 = off & ~3u, sh = off & 3u;
+    __device__ __forceinline__ void load16(uint32_t (&T)[4]) const { load16_at(0, T); }
+    __device__ __forceinline__ void load16_at(int x0, uint32_t (&T)[4]) const {
+        const uint32_t a0 = (off + (uint32_t)x0) & ~3u, sh = (off + (uint32_t)x0) & 3u;
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a0, 0, 0);
         const uint32_t hi = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(a0 + 16u), 0, 0);
         T[0] = __builtin_amdgcn_alignbyte(lo.y, lo.x, sh);
@@ -210,7 +212,6 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
     const uint32_t avail = (uint32_t)a.avail;
     const uint32_t cs = (uint32_t)a.code_shift;
-    const int n_pieces = a.k + 1;
 
     // six dwords of text from the 4-byte aligned position a0: bytes [a0, a0 + 24)
     struct Win { uint32_t w[6]; };
@@ -245,13 +246,11 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
             if (gbyte(s + (uint32_t)x) != (int)s_pat[at + x]) return false;
         if (!PAIRS || side == 0) return true; // no pre-check (k <= 1) / unpaired last piece (even k)
         if (n == 31) { // partner longer than 16 bytes: byte loops (definition of the core, apm_ext_fwd / apm_ext_bwd)
-            const uint32_t ki = a.kinfo[kid];
-            const int kpat = (int)(ki & 0xfffu), q = (int)((ki >> 21) & 7u), p = q ^ 1;
-            const uint2 pinf = a.pinfo[kpat];
-            const int poff = (int)(pinf.x & 0xffffu), m = (int)(pinf.x >> 16), aux = (int)pinf.y;
-            const int ap = (int)a.poff[aux + p], ap1 = (p + 1 < n_pieces) ? (int)a.poff[aux + p + 1] : m, nn = ap1 - ap;
-            auto T = [&](int i) { return p > q ? gbyte(s + (uint32_t)len + (uint32_t)i) : gbyte(s - 1u - (uint32_t)i); };      // text, read away from the piece
-            auto P = [&](int i) { return p > q ? (int)s_pat[poff + ap + i] : (int)s_pat[poff + ap1 - 1 - i]; };                // partner, same direction
+            const uint32_t kp = a.kpart[kid];
+            const int poff = (int)(a.pinfo[a.kinfo[kid] & 0xfffu].x & 0xffffu), ap = (int)(kp & 0xffffu), nn = (int)(kp >> 16), ap1 = ap + nn;
+            const bool fwd = side == 1;
+            auto T = [&](int i) { return fwd ? gbyte(s + (uint32_t)len + (uint32_t)i) : gbyte(s - 1u - (uint32_t)i); };      // text, read away from the exact part
+            auto P = [&](int i) { return fwd ? (int)s_pat[poff + ap + i] : (int)s_pat[poff + ap1 - 1 - i]; };                // partner, same direction
             int i = 0;
             while (i < nn && T(i) == P(i)) ++i;
             if (i >= nn - 1) return true;
@@ -269,7 +268,8 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
         Win tw;
         if (side == 1) { // partner behind the piece: text read forward from the end of the piece
             const uint32_t tp = s + (uint32_t)len;
-            load_win(tp & ~3u, tw);
+            if (len == 0) tw = win; // (a pair of short pieces as one unit: its text starts at s itself)
+            else load_win(tp & ~3u, tw);
             apm_lds_dwords<4>(s_pat, at + len, P);
 #pragma unroll
             for (int i = 0; i < 5; ++i) T[i] = __builtin_amdgcn_alignbyte(tw.w[i + 1], tw.w[i], tp & 3u);
@@ -299,29 +299,63 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
         return apm_ext1_core16(P, T, n);
     };
 
-    // ---- banded DP of the window a nomination implies under shift dl + stateless dedup; bumps s_cnt ----
-    auto dp_item = [&](uint32_t kid, uint32_t s, int dl) __attribute__((always_inline)) {
+    // ---- banded DP of the window a nomination (unit kid at text position s) implies under shift dl ----
+    // on a match: wpat = pattern slot, wj = window start, word = rank of (unit, shift) among the window's nominators
+    auto dp_match = [&](uint32_t kid, uint32_t s, int dl, uint32_t &wpat, uint32_t &wj, uint32_t &word) __attribute__((always_inline)) -> bool {
         const uint32_t ki = a.kinfo[kid];
-        const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kpiece = (int)((ki >> 21) & 7u);
+        const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kunit = (int)((ki >> 21) & 7u);
         const uint2 pinf = a.pinfo[kpat];
-        const int poff = (int)(pinf.x & 0xffffu), m = (int)(pinf.x >> 16), aux = (int)pinf.y;
+        const int poff = (int)(pinf.x & 0xffffu), m = (int)(pinf.x >> 16);
         const int64_t je_p = min(a.je, a.nrel - m + 1);
         const int64_t j = (int64_t)s - koff - dl; // candidate window start
-        if (j < a.jb || j >= je_p) return;
-        if (!apm_banded_verify<BAND>(ApmBufText{rs, (uint32_t)j}, s_pat, poff, m, a.k)) return;
-        // count the window once: only from its first true (piece, shift) nominator
-        for (int qq = 0; qq <= kpiece; ++qq) {
-            const int aq = (int)a.poff[aux + qq];
-            for (int dd = -BAND; dd <= BAND; ++dd) {
-                if (qq == kpiece && dd >= dl) break;
-                const int64_t o = j + aq + dd; // piece start under shift dd
-                if (o < 0) continue;
-                Win w2;
-                load_win((uint32_t)o & ~3u, w2);
-                if (stage1((uint32_t)(kpat * n_pieces + qq), (uint32_t)o, w2)) return;
+        if (j < a.jb || j >= je_p) return false;
+        wpat = (uint32_t)kpat;
+        wj = (uint32_t)j;
+        word = (uint32_t)(kunit * NSH + dl + BAND);
+#ifdef APM_MEASURE
+        atomicAdd(&a.stats[2], 1ull);
+#endif
+        return apm_banded_verify<BAND>(ApmBufText{rs, (uint32_t)j}, s_pat, poff, m, a.k);
+    };
+    // ---- stateless dedup: a matching window counts only from its FIRST true (unit, shift) nominator.  Matches are
+    // rare but come in bursts (an occurrence is nominated by every intact unit, its neighbour windows match too, and
+    // they all sit in one wave).  Among the matches of a round a window is kept by its smallest (unit, shift) only;
+    // what is left is resolved by the whole wave, one match at a time, one lane per earlier (unit, shift): up to
+    // 8 x NSH predicate evaluations with their own text fetches, side by side. ----
+    auto count_matches = [&](bool hit, uint32_t wpat, uint32_t wj, uint32_t word) __attribute__((always_inline)) {
+        for (unsigned long long m2 = __builtin_amdgcn_ballot_w64(hit); m2; m2 &= m2 - 1ull) {
+            const int src = __builtin_ctzll(m2);
+            const uint32_t bpat = (uint32_t)__builtin_amdgcn_readlane((int)wpat, src), bj = (uint32_t)__builtin_amdgcn_readlane((int)wj, src);
+            const uint32_t bord = (uint32_t)__builtin_amdgcn_readlane((int)word, src);
+            if (hit && wpat == bpat && wj == bj && word > bord) hit = false;
+        }
+        unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+        while (hm) {
+            const int src = __builtin_ctzll(hm);
+            hm &= hm - 1ull;
+            const uint32_t bpat = (uint32_t)__builtin_amdgcn_readlane((int)wpat, src), bj = (uint32_t)__builtin_amdgcn_readlane((int)wj, src);
+            const int n_before = __builtin_amdgcn_readlane((int)word, src); // (unit, shift) pairs in front of this one: < 64
+            const uint32_t kid0 = a.pinfo[bpat].y; // the pattern's first unit
+            bool earlier = false;
+#ifdef APM_MEASURE
+            if (APM_SKIP(a, 32)) continue;
+#endif
+            if (lane < n_before) {
+                const int qq = lane / NSH, dd = lane % NSH - BAND;
+                const int64_t o = (int64_t)bj + (int)((a.kinfo[kid0 + (uint32_t)qq] >> 12) & 0x1ffu) + dd; // the unit's text position under shift dd
+                if (o >= 0) {
+                    Win w2;
+                    load_win((uint32_t)o & ~3u, w2);
+                    earlier = stage1(kid0 + (uint32_t)qq, (uint32_t)o, w2);
+                }
+            }
+            if (!__builtin_amdgcn_ballot_w64(earlier) && lane == 0) {
+                atomicAdd(&s_cnt[bpat], 1u);
+#ifdef APM_MEASURE
+                atomicAdd(&a.stats[3], 1ull);
+#endif
             }
         }
-        atomicAdd(&s_cnt[kpat], 1u);
     };
 
     // ---- batches of 64 candidates per wave.  One loop, one stage-1 site, one DP site: each trip either runs the
@@ -361,9 +395,17 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
     bool ex_nn = next_cand(q_nn, have_nn);
     for (;;) {
         if (n_surv >= FLUSH_AT || (done && n_surv)) {
-            for (uint32_t wi = (uint32_t)lane; wi < n_surv * NSH; wi += 64) {
-                const uint2 e = s_surv[wi / NSH];
-                dp_item(e.y, e.x, (int)(wi % NSH) - BAND);
+            for (uint32_t w0 = 0; w0 < n_surv * NSH; w0 += 64) { // one (survivor, shift) per lane
+                const uint32_t wi = w0 + (uint32_t)lane;
+                const bool live = wi < n_surv * NSH;
+                const uint2 e = live ? s_surv[wi / NSH] : make_uint2(0u, 0u);
+                const int dl = (int)(wi % NSH) - BAND;
+                uint32_t wpat = 0, wj = 0, word = 0;
+                bool hit = live && dp_match(e.y, e.x, dl, wpat, wj, word);
+#ifdef APM_MEASURE
+                if (APM_SKIP(a, 64)) hit = false;
+#endif
+                count_matches(hit, wpat, wj, word);
             }
             n_surv = 0;
         }
@@ -410,6 +452,9 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
         if (APM_SKIP(a, 16)) ok = false;
 #endif
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+#ifdef APM_MEASURE
+        if (mask && lane == 0) atomicAdd(&a.stats[1], (unsigned long long)__builtin_popcountll(mask));
+#endif
         if (mask) { // survivors -> the wave's list (ballot + mbcnt, no atomics); at most FLUSH_AT - 1 + 64 entries
             const uint32_t idx = n_surv + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             if (ok) s_surv[idx] = make_uint2(s, cur & 0x7fffu);

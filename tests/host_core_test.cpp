@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 template <int W>
@@ -96,6 +97,77 @@ int main() {
             }
         }
         if (n_true < 100000) { printf("ext1 test saw too few positives\n"); bad++; }
+    }
+    // presence-bitmap windows of a nomination unit (apm_core.h): the constructive enumeration must contain the
+    // brute-force definition, stay close to it in size, and -- the property the sieve relies on -- contain the code word
+    // of ANY text window for which the unit's byte-level predicate holds (exact part intact, partner within one edit)
+    {
+        auto ext1_loop = [](const unsigned char *pb, const unsigned char *tb, int n) {
+            int i = 0;
+            while (i < n && tb[i] == pb[i]) ++i;
+            if (i >= n - 1) return true;
+            bool ok = true;
+            for (int j = i + 1; j < n && ok; ++j) ok = tb[j] == pb[j];
+            if (ok) return true;
+            ok = true;
+            for (int j = i + 1; j < n && ok; ++j) ok = tb[j - 1] == pb[j];
+            if (ok) return true;
+            ok = true;
+            for (int j = i; j < n && ok; ++j) ok = tb[j + 1] == pb[j];
+            return ok;
+        };
+        long words_def = 0, words_gen = 0, positives = 0;
+        std::vector<unsigned char> in_def(65536), in_gen(65536);
+        for (int it = 0; it < 3000; it++) {
+            const char *alphabet = (it % 3 == 0) ? "ACGT" : ((it % 3 == 1) ? "ACGTN\n" : "abcdefgh");
+            const int na = (int)strlen(alphabet);
+            unsigned char pat[40];
+            for (int i = 0; i < 40; i++) pat[i] = (unsigned char)alphabet[rand() % na];
+            ApmUnit u;
+            u.off = rand() % 4;
+            u.len = (it % 4 == 0) ? 0 : 1 + rand() % 12;
+            u.side = (u.len == 0) ? 1 : rand() % 3;
+            u.plen = 1 + rand() % 16;
+            u.poff = u.side == 2 ? 0 : u.off + u.len;
+            if (u.side == 2) { u.off = u.plen; }
+            const int shift = (it % 3 == 2) ? 0 : 1;
+            std::fill(in_def.begin(), in_def.end(), 0);
+            std::fill(in_gen.begin(), in_gen.end(), 0);
+            apm_enum_unit_windows_bruteforce(pat, u, shift, [&](uint32_t x) { in_def[x & 0xffffu] = 1; });
+            apm_enum_unit_windows(pat, u, shift, [&](uint32_t x) { in_gen[x & 0xffffu] = 1; });
+            long nd = 0, ng = 0;
+            for (int x = 0; x < 65536; x++) {
+                nd += in_def[x];
+                ng += in_gen[x];
+                if (in_def[x] && !in_gen[x]) { bad++; if (bad < 5) printf("enum misses word %x (len %d plen %d side %d)\n", x, u.len, u.plen, u.side); break; }
+            }
+            words_def += nd;
+            words_gen += ng;
+            // texts satisfying the predicate: exact part + partner with at most one edit, random bytes elsewhere
+            for (int rep = 0; rep < 40; rep++) {
+                unsigned char text[64];
+                for (int i = 0; i < 64; i++) text[i] = (unsigned char)alphabet[rand() % na];
+                const int s = 24; // unit position
+                for (int i = 0; i < u.len; i++) text[s + i] = pat[u.off + i];
+                if (u.side == 1) {
+                    const int mode = rand() % 4, e = rand() % u.plen;
+                    int w = s + u.len;
+                    for (int i = 0; i < u.plen && w < 60; i++) {
+                        if (mode == 1 && i == e) { text[w++] = (unsigned char)alphabet[rand() % na]; continue; }
+                        if (mode == 2 && i == e) continue;
+                        if (mode == 3 && i == e) text[w++] = (unsigned char)alphabet[rand() % na];
+                        text[w++] = pat[u.poff + i];
+                    }
+                    if (u.plen <= 16 && !ext1_loop(pat + u.poff, text + s + u.len, u.plen)) continue; // (the edit fell badly)
+                }
+                uint32_t x = 0;
+                for (int z = 0; z < 8; z++) x |= (uint32_t)((text[s + z] >> shift) & 3) << (2 * z);
+                positives++;
+                if (!in_gen[x]) { bad++; if (bad < 5) printf("window of a true unit occurrence not enumerated (len %d plen %d side %d)\n", u.len, u.plen, u.side); }
+            }
+        }
+        if (words_gen > words_def * 3 / 2 + 1000) { printf("constructive enumeration too loose: %ld vs %ld\n", words_gen, words_def); bad++; }
+        if (positives < 50000) { printf("unit window test saw too few positives\n"); bad++; }
     }
     // synthetic generator: bytes are ACGT, deterministic
     for (uint64_t i = 0; i < 1000; i++) {

@@ -30,6 +30,8 @@ def run(reps=20):
         ctx.count_shard_device(text.data_ptr(), 0, n, n, 0, n, counts.data_ptr())
         ms.append(ctx.timing()["main_kernel_ms"])
     ms = ms[2:]
+    global last_launches
+    last_launches = ctx.launch_times()
     return min(ms), sum(ms) / len(ms)
 v = text[:n].view(torch.int64)
 for _ in range(3): v.sum()
@@ -43,4 +45,5 @@ print("torch int64 sum over the text: %.3f ms  -> %.0f GB/s" % (t, n / t / 1e6))
 for ab in os.environ.get("ABLATIONS", "0,1,2,3").split(","):
     os.environ["APM_MEASURE_SKIP"] = ab
     mn, av = run()
-    print("ablate=%s  kernel min %.4f ms avg %.4f ms -> %.0f GB/s" % (ab, mn, av, n / mn / 1e6), "counts", counts.tolist()[:8])
+    print("skip=%s  kernel min %.4f ms avg %.4f ms -> %.0f GB/s" % (ab, mn, av, n / mn / 1e6), "counts", counts.tolist()[:8],
+          [(l, round(t, 4)) for l, t in last_launches])
