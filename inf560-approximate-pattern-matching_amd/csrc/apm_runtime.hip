@@ -88,9 +88,9 @@ struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns 
     std::vector<uint32_t> kpart;      // per key: partner offset inside the pattern | partner length << 16
     std::vector<uint32_t> pinfo;      // per pattern: {byte_off | m << 16, id of its first key}
     std::vector<uint8_t> image;       // bitmap16 | prefix | r2s | slots | kext | pattern bytes
-    int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0;
+    int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0, o_masks = 0;
     int m_max = 0, m_min = 0;
-    int blocks_per_cu = 0;            // occupancy query, cached
+    int blocks_per_cu = 0, threads = 256; // launch geometry (occupancy query, cached)
 };
 
 struct SievePlan {         // ONE text pass (apm_sieve2_kernel) for every per-position key of the pattern set
@@ -491,6 +491,12 @@ int build_sieve_plan(apm_ctx *ctx) {
         V.o_r2s = append(r2s.data(), r2s.size() * 2);
         V.o_slots = append(slots.data(), slots.size() * 2);
         V.o_kext = append(kext.data(), kext.size() * 4);
+        {
+            std::vector<uint8_t> masks(17 * 16, 0);
+            for (int n = 0; n <= 16; ++n)
+                for (int b = 0; b < n; ++b) masks[(size_t)n * 16 + (size_t)b] = 0xff;
+            V.o_masks = append(masks.data(), masks.size());
+        }
         V.o_pat = append(V.bytes.data(), V.bytes.size());
         S.m_max = std::max(S.m_max, V.m_max);
         S.launches.push_back(std::move(V));
@@ -1042,6 +1048,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 va.o_slots = V.o_slots;
                 va.o_kext = V.o_kext;
                 va.o_pat = V.o_pat;
+                va.o_masks = V.o_masks;
                 va.kinfo = ds.verify[v].d_kinfo;
                 va.pinfo = reinterpret_cast<const uint2 *>(ds.verify[v].d_pinfo);
                 va.kpart = ds.verify[v].d_kpart;
@@ -1060,8 +1067,8 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
 #ifdef APM_MEASURE
                 va.stats = ds.d_cand + 2;
 #endif
-                if (!V.blocks_per_cu) V.blocks_per_cu = apm_verify_blocks_per_cu(va);
-                HIP_TRY(ctx, apm_launch_verify(va, ds.n_cu * V.blocks_per_cu, ds.stream));
+                if (!V.blocks_per_cu) V.blocks_per_cu = apm_verify_geometry(va, &V.threads);
+                HIP_TRY(ctx, apm_launch_verify(va, V.threads, ds.n_cu * V.blocks_per_cu, ds.stream));
                 { const int nrc = note_launch(ctx, ds, "verify"); if (nrc) return nrc; }
             }
             sieve_run = true;
@@ -1821,6 +1828,7 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }
     if (n == "verify_image_bytes") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].image.size(); return APM_OK; }
     if (n == "verify_blocks_per_cu") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].blocks_per_cu; return APM_OK; }
+    if (n == "verify_threads") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].threads; return APM_OK; }
     if (n == "sieve_candidates" || n == "sieve_overflow" || n.rfind("verify_", 0) == 0) { // of the last call (synchronises with the stream)
         if (!ds.d_cand) { *value = 0; return APM_OK; }
         HIP_TRY(ctx, hipSetDevice(ds.dev));

@@ -52,6 +52,7 @@ struct ApmVerifyArgs {
        kext: u32 per key (see ApmFilterArgs::o_kext) | raw pattern bytes */
     const uint4 *image;
     int image_len, o_prefix, o_r2s, o_slots, o_kext, o_pat;
+    int o_masks;                /* 17 x 16 bytes: entry n = n leading 0xff bytes (byte masks of a compare of n <= 16 bytes) */
     /* the records only the (rare) banded DP needs stay in global memory */
     const uint32_t *kinfo;      /* per key = nomination unit: pat | off << 12 | unit index inside the pattern << 21; off = offset of
                                    the unit's text position inside the window (window start = position - off - shift) */
@@ -73,8 +74,7 @@ struct ApmVerifyArgs {
 };
 
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s);
-hipError_t apm_launch_verify(const ApmVerifyArgs &a, int max_blocks, hipStream_t s);
-size_t apm_verify_lds_bytes(const ApmVerifyArgs &a);
-int apm_verify_blocks_per_cu(const ApmVerifyArgs &a);
+hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, hipStream_t s);
+int apm_verify_geometry(const ApmVerifyArgs &a, int *threads); /* workgroups per CU; *threads = 256 or 512 */
 
 #endif /* APM_SIEVE_H */

@@ -173,8 +173,10 @@ struct ApmBufText {
 
 __host__ __device__ constexpr int apm_verify_scap(int band) { return ((64 + 2 * band) / (2 * band + 1) + 63 + 7) & ~7; }
 
-template <int BAND>
-__global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs a) {
+// THREADS = 256 or 512: the bigger workgroup shares one LDS image among eight waves -- more waves per CU when the
+// image (many keys) limits the workgroups per CU
+template <int BAND, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,17 +192,18 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
     const uint16_t *s_slots = reinterpret_cast<const uint16_t *>(s_img + a.o_slots);
     const uint32_t *s_kext = reinterpret_cast<const uint32_t *>(s_img + a.o_kext);
     const uint8_t *s_pat = s_img + a.o_pat;
+    const uint4 *s_masks = reinterpret_cast<const uint4 *>(s_img + a.o_masks);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_img + a.image_len);
     uint2 *s_surv = reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + wv * SCAP; // this wave's survivors {position, kid}
-    uint32_t *s_rc = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + (APM_BLOCK / 64) * SCAP); // [SHARDS] candidates in list region s
+    uint32_t *s_rc = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + (THREADS / 64) * SCAP); // [SHARDS] candidates in list region s
     uint32_t *s_pre = s_rc + APM_CAND_SHARDS;                                                                                     // [SHARDS + 1] 64-candidate batches before region s
 
-    for (int i = tid; i < (a.image_len >> 4); i += APM_BLOCK) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
-    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
-    static_assert(APM_CAND_SHARDS == APM_BLOCK, "one thread per list region below");
-    s_rc[tid] = (uint32_t)a.shard_cnt[16 * tid]; // (<= shard_cap < 2^32: no overflow happened)
+    for (int i = tid; i < (a.image_len >> 4); i += THREADS) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
+    for (int i = tid; i < a.n_pats; i += THREADS) s_cnt[i] = 0u;
+    static_assert(APM_CAND_SHARDS <= THREADS, "one thread per list region below");
+    if (tid < APM_CAND_SHARDS) s_rc[tid] = (uint32_t)a.shard_cnt[16 * tid]; // (<= shard_cap < 2^32: no overflow happened)
     __syncthreads();
-    {
+    if (tid < APM_CAND_SHARDS) {
         uint32_t before = 0;
         for (int i = 0; i < tid; ++i) before += (s_rc[i] + 63u) >> 6;
         s_pre[tid] = before;
@@ -238,10 +241,8 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i) A[i] = __builtin_amdgcn_alignbyte(win.w[i + 1], win.w[i], sh); // text bytes [s, s+16)
         apm_lds_dwords<4>(s_pat, at, B);
-        const u64 ml = len >= 8 ? ~0ull : ((1ull << (8 * len)) - 1ull);
-        const u64 mh = len <= 8 ? 0ull : (len >= 16 ? ~0ull : ((1ull << (8 * (len - 8))) - 1ull));
-        const u64 dl = (((u64)(A[1] ^ B[1]) << 32) | (A[0] ^ B[0])) & ml, dh = (((u64)(A[3] ^ B[3]) << 32) | (A[2] ^ B[2])) & mh;
-        if ((dl | dh) != 0ull) return false; // the piece is not intact
+        const uint4 mk = s_masks[len < 16 ? len : 16]; // 0xff for the first min(len, 16) bytes
+        if ((((A[0] ^ B[0]) & mk.x) | ((A[1] ^ B[1]) & mk.y) | ((A[2] ^ B[2]) & mk.z) | ((A[3] ^ B[3]) & mk.w)) != 0u) return false; // the exact part is not intact
         for (int x = 16; x < len; ++x)       // (pieces beyond 16 bytes: patterns with long pieces in this class)
             if (gbyte(s + (uint32_t)x) != (int)s_pat[at + x]) return false;
         if (!PAIRS || side == 0) return true; // no pre-check (k <= 1) / unpaired last piece (even k)
@@ -295,6 +296,18 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
             for (int z = 0; z < 4; ++z) P[z] = apm_bswap(Q[3 - z]);
 #pragma unroll
             for (int z = 0; z < 5; ++z) T[z] = apm_bswap(Wd[4 - z]);
+        }
+        // necessary first: the partner's first four bytes within one edit (a prefix of an alignment with <= 1 edit has
+        // <= 1 edit): nonzero-byte masks of P ^ T under the three alignments, 4 bits each; rejects ~9 of 10 random texts
+        if (n >= 4) {
+            auto nz4 = [](uint32_t x) { return apm_udot4((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7 & 0x01010101u, 0x08040201u); };
+            const uint32_t z0 = nz4(P[0] ^ T[0]);
+            if (z0 & (z0 - 1u)) { // two or more mismatching bytes under the substitution alignment
+                const uint32_t i = (uint32_t)__builtin_ctz(z0); // first mismatching byte: 0..2
+                const uint32_t z1 = nz4(P[0] ^ (T[0] << 8));                                  // pattern byte i has no text counterpart
+                const uint32_t z2 = nz4(P[0] ^ __builtin_amdgcn_alignbyte(T[1], T[0], 1u));   // one extra text byte before pattern byte i
+                if (((z1 >> (i + 1u)) != 0u) && ((z2 >> i) != 0u)) return false;
+            }
         }
         return apm_ext1_core16(P, T, n);
     };
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
     uint32_t n_surv = 0; // wave-uniform
     // the batches of all regions, in region order, are dealt to the waves in equal contiguous runs
     const uint32_t n_batches = s_pre[APM_CAND_SHARDS];
-    const uint32_t n_waves = (uint32_t)a.n_blocks * (APM_BLOCK / 64), my_wave = blockIdx.x * (APM_BLOCK / 64) + (uint32_t)wv;
+    const uint32_t n_waves = (uint32_t)a.n_blocks * (THREADS / 64), my_wave = blockIdx.x * (THREADS / 64) + (uint32_t)wv;
     uint32_t bi = (uint32_t)(((unsigned long long)n_batches * my_wave) / n_waves);
     const uint32_t b_end = (uint32_t)(((unsigned long long)n_batches * (my_wave + 1u)) / n_waves);
     uint32_t sh = 0; // region of batch bi: the last one with s_pre[sh] <= bi
@@ -467,40 +480,55 @@ __global__ __launch_bounds__(APM_BLOCK, 4) void apm_verify_kernel(ApmVerifyArgs 
     }
 
     __syncthreads();
-    for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
+    for (int i = tid; i < a.n_pats; i += THREADS) {
         const uint32_t cnt = s_cnt[i];
         if (cnt) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)cnt);
     }
 }
 
-size_t apm_verify_lds_bytes(const ApmVerifyArgs &a) {
-    return (size_t)a.image_len + (size_t)((a.n_pats + 3) & ~3) * 4 + (size_t)(APM_BLOCK / 64) * (size_t)apm_verify_scap(a.band) * 8 +
-           (size_t)(2 * APM_CAND_SHARDS + 4) * 4 + 16; // image + counts + 4 survivor lists + region tables
+static size_t apm_verify_lds_bytes_t(const ApmVerifyArgs &a, int threads) {
+    return (size_t)a.image_len + (size_t)((a.n_pats + 3) & ~3) * 4 + (size_t)(threads / 64) * (size_t)apm_verify_scap(a.band) * 8 +
+           (size_t)(2 * APM_CAND_SHARDS + 4) * 4 + 16; // image + counts + one survivor list per wave + region tables
 }
 
-static const void *apm_verify_fn(int band) {
-    switch (band) {
-    case 0: return (const void *)apm_verify_kernel<0>;
-    case 1: return (const void *)apm_verify_kernel<1>;
-    case 2: return (const void *)apm_verify_kernel<2>;
-    case 3: return (const void *)apm_verify_kernel<3>;
+static const void *apm_verify_fn(int band, int threads) {
+    switch (band * 2 + (threads == 512 ? 1 : 0)) {
+    case 0: return (const void *)apm_verify_kernel<0, 256>;
+    case 1: return (const void *)apm_verify_kernel<0, 512>;
+    case 2: return (const void *)apm_verify_kernel<1, 256>;
+    case 3: return (const void *)apm_verify_kernel<1, 512>;
+    case 4: return (const void *)apm_verify_kernel<2, 256>;
+    case 5: return (const void *)apm_verify_kernel<2, 512>;
+    case 6: return (const void *)apm_verify_kernel<3, 256>;
+    case 7: return (const void *)apm_verify_kernel<3, 512>;
     default: return nullptr;
     }
 }
 
-int apm_verify_blocks_per_cu(const ApmVerifyArgs &a) {
-    int per_cu = 0;
-    const void *fn = apm_verify_fn(a.band);
-    if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, APM_BLOCK, apm_verify_lds_bytes(a)) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = 2;
+// workgroup size (256 or 512 threads) and workgroups per CU that put the most waves on a CU for this LDS image
+int apm_verify_geometry(const ApmVerifyArgs &a, int *threads) {
+    int best_waves = 0, best_blocks = 2;
+    *threads = 256;
+    for (int t : {256, 512}) {
+        int per_cu = 0;
+        const void *fn = apm_verify_fn(a.band, t);
+        if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, t, apm_verify_lds_bytes_t(a, t)) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            continue;
+        }
+        per_cu = per_cu > 8 ? 8 : per_cu;
+        if (per_cu * (t / 64) > best_waves) {
+            best_waves = per_cu * (t / 64);
+            best_blocks = per_cu;
+            *threads = t;
+        }
     }
-    return per_cu > 8 ? 8 : per_cu;
+    return best_blocks;
 }
 
-hipError_t apm_launch_verify(const ApmVerifyArgs &a, int max_blocks, hipStream_t s) {
+hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, hipStream_t s) {
     if (a.n_pats <= 0) return hipSuccess;
-    const void *fn = apm_verify_fn(a.band);
+    const void *fn = apm_verify_fn(a.band, threads);
     if (!fn) return hipErrorInvalidValue;
     ApmVerifyArgs args = a;
     args.n_blocks = max_blocks < 1 ? 1 : max_blocks; // (list length unknown on the host: a persistent grid strides over it)
@@ -508,5 +536,5 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int max_blocks, hipStream_t
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
 #endif
     void *kargs[] = {&args};
-    return hipLaunchKernel(fn, dim3((unsigned)args.n_blocks), dim3(APM_BLOCK), kargs, apm_verify_lds_bytes(a), s);
+    return hipLaunchKernel(fn, dim3((unsigned)args.n_blocks), dim3((unsigned)threads), kargs, apm_verify_lds_bytes_t(a, threads), s);
 }
