@@ -128,6 +128,8 @@ struct DeviceState {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
+    hipStream_t side_stream = nullptr;        // the guarded fallback launches of the sieve pipeline run beside the verify launches
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *d_allpat = nullptr;              // every pattern's raw bytes, concatenated
     ApmPatDesc *d_tail_descs = nullptr;       // tails of tiled-kernel patterns with m > 128 (generic kernel)
     ApmPatDesc *d_stail_descs = nullptr;      // tails of tiled-kernel patterns with m <= 128 (tail kernel)
@@ -1030,6 +1032,10 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             }
             HIP_TRY(ctx, apm_launch_sieve2(sv, ds.n_cu, ds.stream));
             { const int nrc = note_launch(ctx, ds, "sieve"); if (nrc) return nrc; }
+            // the guarded fallback launches (no-ops unless the list overflowed) go to a side stream behind the sieve and
+            // run beside the verify launches instead of adding their kernel boundaries to the step
+            HIP_TRY(ctx, hipEventRecord(ds.ev_fork, ds.stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ds.side_stream, ds.ev_fork, 0));
             for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
                 VerifyLaunch &V = ctx->sieve.launches[v];
                 const int64_t je_v = std::min<int64_t>(je, nrel - V.m_min + 1);
@@ -1150,8 +1156,9 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                     f.tail = ta;
                     tails_pending = false;
                 }
-                HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
-                { const int nrc = note_launch(ctx, ds, sieved ? "stream(fallback)" : "stream"); if (nrc) return nrc; }
+                HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], sieved ? ds.side_stream : ds.stream));
+                if (sieved) ds.launches++;
+                else { const int nrc = note_launch(ctx, ds, "stream"); if (nrc) return nrc; }
                 continue;
             }
             if (!ctx->tiled[t].blocks_per_cu[f.use_dma])
@@ -1168,9 +1175,10 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 static const int bpc_env = getenv("APM_BPC_CAP") ? atoi(getenv("APM_BPC_CAP")) : 0;
                 if (bpc_env > 0) bpc = std::min(bpc_env, bpc);
 #endif
-                HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * bpc, ds.stream));
+                HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * bpc, sieved ? ds.side_stream : ds.stream));
             }
-            { const int nrc = note_launch(ctx, ds, f.cand_mode == 2 ? "tile(fallback)" : "tile"); if (nrc) return nrc; }
+            if (sieved) ds.launches++;
+            else { const int nrc = note_launch(ctx, ds, "tile"); if (nrc) return nrc; }
             continue;
         }
         ApmScanArgs a{};
@@ -1195,6 +1203,10 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         if (L.kind == APM_KERNEL_BITPAR) HIP_TRY(ctx, apm_launch_bitpar(a, ds.stream));
         else HIP_TRY(ctx, apm_launch_wavefront(a, ds.stream));
         { const int nrc = note_launch(ctx, ds, (L.kind == APM_KERNEL_BITPAR ? "bitpar" : "wavefront")); if (nrc) return nrc; }
+    }
+    if (sieve_run) { // the side stream's launches belong to this call
+        HIP_TRY(ctx, hipEventRecord(ds.ev_join, ds.side_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ds.stream, ds.ev_join, 0));
     }
     int rc = launch_generic_group(ctx, ds, ctx->longs, ds.d_long_descs, 2, d_text, avail, jb, je, nrel, d_counts, sink);
     if (rc) return rc;
@@ -1368,6 +1380,9 @@ int init_device(apm_ctx *ctx, DeviceState &ds, int dev) {
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) ds.n_cu = ncu;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ds.own_stream, hipStreamNonBlocking));
     ds.stream = ds.own_stream;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ds.side_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreate(&ds.ev_start));
     HIP_TRY(ctx, hipEventCreate(&ds.ev_kstart));
     HIP_TRY(ctx, hipEventCreate(&ds.ev_mstart));
@@ -1504,6 +1519,8 @@ void apm_destroy(apm_ctx *ctx) {
         for (hipEvent_t e : ds.ev_stage) if (e) hipEventDestroy(e);
         for (hipEvent_t e : ds.ev_launch) if (e) hipEventDestroy(e);
         for (hipEvent_t e : {ds.ev_start, ds.ev_kstart, ds.ev_mstart, ds.ev_mstop, ds.ev_stop}) if (e) hipEventDestroy(e);
+        if (ds.side_stream) hipStreamSynchronize(ds.side_stream), hipStreamDestroy(ds.side_stream);
+        for (hipEvent_t e : {ds.ev_fork, ds.ev_join}) if (e) hipEventDestroy(e);
         if (ds.own_stream) hipStreamDestroy(ds.own_stream);
     }
     for (int b = 0; b < apm_ctx::N_STAGE; ++b)

@@ -526,6 +526,40 @@ def test_text_beyond_4gib_on_device(ctx, apm):
     assert t["text_bytes"] >= n
 
 
+def test_sieve_pipeline_and_tile_kernels_agree_beyond_4gib(apm):
+    """5 GiB of device text with BASELINE cfg3's pattern set: as ONE shard it is beyond the sieve + verify pipeline's
+    32-bit offsets and runs on the LDS-tile / stream kernels; cut into two owner-computes shards (each < 4 GiB) it runs
+    through the pipeline.  Same counts, planted occurrences found (64-bit positions, shard seams, both kernel families)."""
+    import torch
+    wl = H.workloads()
+    c = wl.CONFIGS["cfg3"]
+    n, k, seed = 5 << 30, c["k"], wl.seed_of(c["cid"])
+    pats, planted = wl.make_patterns(n, c["lens"], k, seed)
+    P, m_max = len(pats), max(len(p) for p in pats)
+    text = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+    cnt = torch.zeros(P, dtype=torch.int64, device="cuda:0")
+    with apm.ApmContext(device=0) as c2:
+        c2.set_patterns(pats, k)
+        assert c2.stat("sieve_on") == 1
+        c2.synth_fill_device(text.data_ptr(), 0, n, seed)
+        c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())
+        c2.synchronize()
+        whole = cnt.cpu().tolist()
+        assert c2.stat("sieve_candidates") == 0          # the one-shard call did not use the pipeline
+        cnt.zero_()
+        torch.cuda.synchronize()
+        cut = (n // 2 + 12345) & ~15
+        for lo, hi in ((0, cut), (cut, n)):
+            end = min(n, hi + m_max - 1)
+            c2.count_shard_device(text.data_ptr() + lo, lo, end - lo, n, lo, hi, cnt.data_ptr())
+            c2.synchronize()
+            assert c2.stat("sieve_candidates") > 0 and c2.stat("sieve_overflow") == 0
+        assert cnt.cpu().tolist() == whole
+    for cc, (o, d) in zip(whole, planted):
+        assert cc >= (1 if d <= k else 0)
+    del text
+
+
 def test_cli_file_larger_than_2gib(tmp_path_factory, apm):
     """apm_parallel on a 2.25 GiB file (64-bit chunked ingest) == device-resident scan of the same bytes"""
     if not os.path.exists(CLI):
