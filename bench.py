@@ -127,7 +127,8 @@ def cpu_baseline(apm, pats, k, seed, gpu_slice_counts_fn):
 
 def wavefront_wave_instr(lens, positions):
     """VALU wave-instructions the WAVEFRONT kernel issues (from the gfx950 disassembly of wf_scan: 10 per lane-step +
-    6 per row of the lane, packed 16-bit = two windows per register; S = 64/Lm window pairs per sweep)."""
+    6 per row of the lane, packed 16-bit = two windows per register; S = 64/Lm window pairs per sweep); within 3 % of
+    SQ_INSTS_VALU measured on the cfg2 pass (profiles/r02/pmc_fulldp_cfg2.txt)."""
     total = 0.0
     for m in lens:
         best = None
@@ -144,8 +145,9 @@ def wavefront_wave_instr(lens, positions):
 
 
 def bitpar_wave_instr(lens, positions):
-    """BITPAR: one window per lane, ~14 VALU per 32-row word and column (apm_core.h bp_step) + 3 for the Eq fetch."""
-    return sum(m * (14.0 * ((m + 31) // 32) + 3.0) for m in lens) * positions / 64.0
+    """BITPAR: one window per lane; 13.7 VALU wave-instructions per column at one 32-row word (SQ_INSTS_VALU of the
+    cfg2 pass, profiles/r02/pmc_fulldp_cfg2.txt), ~10.7 more per further word (apm_core.h bp_step)."""
+    return sum(m * (10.7 * ((m + 31) // 32) + 3.0) for m in lens) * positions / 64.0
 
 
 def main():

@@ -147,7 +147,13 @@ int apm_find_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, int pattern_i
  * Requires text_off <= own_begin and
  *          text_off+text_len >= min(n_total, own_end + m_max - 1).
  * d_counts: device array of n_patterns uint64, ADDED into (caller zeroes it).
- * Work is enqueued on the context's stream; no host synchronisation. */
+ * Work is enqueued on the context's stream.  In the steady state the call does not synchronise with the host; the
+ * FIRST call with a pattern set, and a call that needs larger scratch than any before it (the sieve's candidate
+ * list grows with text_len; the GENERIC kernel's columns), allocate device memory and may synchronise the stream.
+ * Readable padding: the scan kernels fetch 16 bytes at a time, so the memory behind d_text must be readable up to
+ * the next 16-byte boundary past d_text + text_len, and (for a d_text that is not 16-byte aligned) back to the
+ * 16-byte boundary in front of it -- both lie inside any hipMalloc'ed block if the block is 16 bytes larger than
+ * the text.  Those bytes are never part of a counted window. */
 int apm_count_shard_device(apm_ctx *ctx, const void *d_text, uint64_t text_off,
                            uint64_t text_len, uint64_t n_total,
                            uint64_t own_begin, uint64_t own_end,
@@ -181,7 +187,7 @@ int apm_get_launch_times(const apm_ctx *ctx, int max, double *ms, const char **l
 /* Named statistics of the plan / the last counting call on device 0 (introspection for benchmarks and DESIGN.md):
  * "sieve_on", "sieve_rate" (expected candidates per even text position), "sieve_capacity" (list entries),
  * "sieve_candidates", "sieve_overflow" (last call; these two synchronise with the stream), "verify_launches",
- * "verify_image_bytes", "verify_blocks_per_cu".  Unknown names: APM_ERR_INVALID. */
+ * "verify_image_bytes", "verify_blocks_per_cu", "verify_threads".  Unknown names: APM_ERR_INVALID. */
 int apm_get_stat(const apm_ctx *ctx, const char *name, double *value);
 /* Kernel variant AUTO (or the forced variant) resolves to for pattern i. */
 int apm_pattern_kernel(const apm_ctx *ctx, int i);

@@ -201,14 +201,30 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
     for (int i = tid; i < (a.image_len >> 4); i += THREADS) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
     for (int i = tid; i < a.n_pats; i += THREADS) s_cnt[i] = 0u;
     static_assert(APM_CAND_SHARDS <= THREADS, "one thread per list region below");
-    if (tid < APM_CAND_SHARDS) s_rc[tid] = (uint32_t)a.shard_cnt[16 * tid]; // (<= shard_cap < 2^32: no overflow happened)
-    __syncthreads();
+    // batches (64 candidates) per list region and their exclusive prefix sums: regions 64 w .. 64 w + 63 are scanned by
+    // wave w with DPP-free shuffles, the four wave totals are added up through LDS
+    uint32_t my_nb = 0, incl = 0;
     if (tid < APM_CAND_SHARDS) {
-        uint32_t before = 0;
-        for (int i = 0; i < tid; ++i) before += (s_rc[i] + 63u) >> 6;
-        s_pre[tid] = before;
-        if (tid == APM_CAND_SHARDS - 1) s_pre[APM_CAND_SHARDS] = before + ((s_rc[tid] + 63u) >> 6);
+        const uint32_t rc = (uint32_t)a.shard_cnt[16 * tid]; // (<= shard_cap < 2^32: no overflow happened)
+        s_rc[tid] = rc;
+        my_nb = (rc + 63u) >> 6;
+        incl = my_nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_pre[APM_CAND_SHARDS - 3 + wv] = incl; // (wave totals parked in slots this wave range never reads back early)
     }
+    __syncthreads();
+    uint32_t wave_base = 0;
+    if (tid < APM_CAND_SHARDS) {
+        for (int w = 0; w < wv; ++w) wave_base += s_pre[APM_CAND_SHARDS - 3 + w];
+    }
+    const uint32_t total_nb = s_pre[APM_CAND_SHARDS - 3] + s_pre[APM_CAND_SHARDS - 2] + s_pre[APM_CAND_SHARDS - 1] + s_pre[APM_CAND_SHARDS];
+    __syncthreads();
+    if (tid < APM_CAND_SHARDS) s_pre[tid] = wave_base + incl - my_nb;
+    if (tid == 0) s_pre[APM_CAND_SHARDS] = total_nb;
     __syncthreads(); // the last workgroup barrier before the final count flush
 
     const __amdgpu_buffer_rsrc_t rs =
