@@ -20,7 +20,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <sys/time.h>
+#include <unistd.h>
 
 #include "apm.h"
 
@@ -145,25 +149,21 @@ int main(int argc, char **argv) {
         printf("Number of matches for pattern <%s>: %llu\n", argv[i + 3], (unsigned long long)n_matches[i]);
 
     if (want_positions) { /* off by default: stdout stays identical to the reference */
-        FILE *f = fopen(filename, "rb");
+        /* the text is mapped, not read a second time into a heap buffer */
         uint8_t *buf = NULL;
-        uint64_t n = 0, cap = 0;
-        if (f) {
-            for (;;) {
-                if (n == cap) {
-                    cap = cap ? cap * 2 : ((uint64_t)1 << 20);
-                    uint8_t *nb = (uint8_t *)realloc(buf, (size_t)cap);
-                    if (!nb) { free(buf); buf = NULL; break; }
-                    buf = nb;
-                }
-                const size_t r = fread(buf + n, 1, (size_t)(cap - n), f);
-                if (!r) break;
-                n += r;
+        uint64_t n = 0;
+        const int fd = open(filename, O_RDONLY);
+        struct stat st;
+        if (fd >= 0 && fstat(fd, &st) == 0 && st.st_size > 0) {
+            void *mp = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (mp != MAP_FAILED) {
+                buf = (uint8_t *)mp;
+                n = (uint64_t)st.st_size;
             }
-            fclose(f);
         }
-        if (!buf && n) {
-            fprintf(stderr, "Unable to allocate memory for the positions pass\n");
+        if (fd >= 0) close(fd);
+        if (!buf && fd >= 0 && st.st_size > 0) {
+            fprintf(stderr, "Unable to map the text file for the positions pass\n");
             apm_destroy(ctx);
             return 1;
         }
@@ -180,7 +180,7 @@ int main(int argc, char **argv) {
             printf(found > pcap ? " ...\n" : "\n");
         }
         free(pos);
-        free(buf);
+        if (buf) munmap(buf, (size_t)n);
     }
 
     apm_destroy(ctx);
