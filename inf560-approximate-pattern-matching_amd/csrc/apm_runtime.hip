@@ -96,9 +96,10 @@ struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns 
 
 struct SievePlan {         // ONE text pass (apm_sieve2_kernel) for every per-position key of the pattern set
     bool on = false;
+    int stride = 1;                   // 1: every position (per-position keys present); 8: sampled (all pieces >= 15 bytes)
     int code_shift = 1;
     int m_max = 0;
-    double rate = 0;                  // expected hits per even text position on uniform codes (bitmap density)
+    double rate = 0;                  // expected hits per lookup on uniform codes (bitmap density)
     std::vector<uint32_t> bitmap;     // 32 KiB over the 18-bit code words of 9-byte windows: dword x & 8191, bit x >> 13
     std::vector<VerifyLaunch> launches;
 };
@@ -369,8 +370,9 @@ void mark_key_windows(std::vector<uint8_t> &bmp, const TiledLaunch &L, const Apm
 
 // Plan of the sieve + verify pipeline for all BANDED patterns of the set (see build_plan).  Leaves ctx->sieve.on
 // false when the key set is too dense or does not fit the pipeline's limits.
-int build_sieve_plan(apm_ctx *ctx) {
+int build_sieve_plan(apm_ctx *ctx, int stride) {
     SievePlan &S = ctx->sieve;
+    S.stride = stride;
     const int P = (int)ctx->pats.size();
     const int pieces = ctx->k + 1;
     const bool pairs = ctx->k / 2 >= 1;
@@ -423,7 +425,7 @@ int build_sieve_plan(apm_ctx *ctx) {
         std::vector<ApmUnit> units; // per key, offsets relative to the pattern
         for (; pos < idx.size(); ++pos) {
             const PatternInfo &pi = ctx->pats[idx[pos]];
-            if (!V.descs.empty() && (V.bytes.size() + (size_t)pi.m > 24576 || V.kinfo.size() + (size_t)pieces > 8192 || V.descs.size() >= 4096))
+            if (!V.descs.empty() && (V.bytes.size() + (size_t)pi.m > 24576 || V.kinfo.size() + (size_t)pieces > (stride == 8 ? 2048u : 8192u) || V.descs.size() >= 4096))
                 break;
             ApmPatDesc d{};
             d.m = (uint32_t)pi.m;
@@ -452,8 +454,18 @@ int build_sieve_plan(apm_ctx *ctx) {
         for (size_t kid = 0; kid < units.size(); ++kid) {
             const ApmUnit &u = units[kid];
             const ApmPatDesc &dd = V.descs[V.kinfo[kid] & 0xfffu];
-            apm_enum_unit_windows(V.bytes.data() + dd.byte_off, u, S.code_shift,
-                                  [&](uint32_t xx) { wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | (uint64_t)kid); });
+            if (stride == 8) {
+                // sampled: whatever the piece's position, one of its blocks [r, r+8), r = 0..7, starts at a multiple of 8 in
+                // the text; the key-list payload carries r above the key id (11 bits)
+                for (uint32_t r = 0; r < 8; ++r) {
+                    uint32_t xx = 0;
+                    for (int z = 0; z < 8; ++z) xx |= (uint32_t)((V.bytes[dd.byte_off + (uint32_t)u.off + r + (uint32_t)z] >> S.code_shift) & 3) << (2 * z);
+                    wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | (uint64_t)(kid | (r << 11)));
+                }
+            } else {
+                apm_enum_unit_windows(V.bytes.data() + dd.byte_off, u, S.code_shift,
+                                      [&](uint32_t xx) { wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | (uint64_t)kid); });
+            }
             // packed pre-check record: byte offset of the exact part in the pattern pool | its length << 16 |
             // partner length << 24 (31 = beyond 16) | side << 29
             kext.push_back((uint32_t)(dd.byte_off + (uint32_t)u.off) | (std::min<uint32_t>((uint32_t)u.len, 255u) << 16) |
@@ -504,12 +516,17 @@ int build_sieve_plan(apm_ctx *ctx) {
         S.m_max = std::max(S.m_max, V.m_max);
         S.launches.push_back(std::move(V));
     }
-    // the sieve's bitmap over 9-byte windows at EVEN positions: a key window (16-bit word x) may start at the even
-    // position (then the ninth byte is free) or at the odd one behind it (then the first byte is free)
+    // the sieve's bitmap.  Stride 1: over 9-byte windows at EVEN positions -- a key window (16-bit word x) may start at
+    // the even position (then the ninth byte is free) or at the odd one behind it (then the first byte is free).
+    // Stride 8: the 16-bit words themselves (dword x & 2047, bit x >> 11).
     long pop16 = 0, pop18 = 0;
     for (uint32_t x = 0; x < 65536u; ++x) {
         if (!((seen16[x & 8191u] >> (x >> 13)) & 1u)) continue;
         ++pop16;
+        if (stride == 8) {
+            S.bitmap[x & 2047u] |= 1u << (x >> 11);
+            continue;
+        }
         for (uint32_t f = 0; f < 4; ++f) {
             for (const uint32_t c18 : {x | (f << 16), (x << 2) | f}) {
                 uint32_t &w = S.bitmap[c18 & 8191u];
@@ -519,7 +536,7 @@ int build_sieve_plan(apm_ctx *ctx) {
         }
     }
     if (pop16 > 6553) return APM_OK;
-    S.rate = (double)pop18 / 262144.0;
+    S.rate = stride == 8 ? (double)pop16 / 65536.0 : (double)pop18 / 262144.0;
     S.on = !S.launches.empty();
     return APM_OK;
 }
@@ -652,11 +669,18 @@ int build_plan(apm_ctx *ctx) {
     ctx->sieve = SievePlan();
     {
         static const int sieve_env = getenv("APM_SIEVE") ? atoi(getenv("APM_SIEVE")) : 1;
-        bool has_s1 = false;
-        for (int i = 0; i < P; ++i)
-            if (ctx->pats[i].kernel == APM_KERNEL_BANDED && ctx->pats[i].m / (ctx->k + 1) < 15) has_s1 = true;
-        if (sieve_env && has_s1) {
-            const int rc = build_sieve_plan(ctx);
+        bool has_s1 = false, has_banded = false;
+        for (int i = 0; i < P; ++i) {
+            if (ctx->pats[i].kernel != APM_KERNEL_BANDED) continue;
+            has_banded = true;
+            if (ctx->pats[i].m / (ctx->k + 1) < 15) has_s1 = true;
+        }
+        // sets of long pieces only: the sampled form of the pipeline (one lookup per 8 bytes) when verification is the
+        // heavy part (k >= 2: pair pre-check + banded DP, which stall the stream kernel's loads); with k <= 1 the stream
+        // kernel already sits on the HBM ceiling (cfg2) and a second launch would only add its fixed cost
+        const int stride = has_s1 ? 1 : 8;
+        if (sieve_env && has_banded && (has_s1 || ctx->k >= 2)) {
+            const int rc = build_sieve_plan(ctx, stride);
             if (rc) return rc;
         }
     }
@@ -668,7 +692,7 @@ int build_plan(apm_ctx *ctx) {
         const int stride = st_of[cls];
         auto class_of = [&](int m) {
             const int piece = m / (ctx->k + 1);
-            if (ctx->sieve.on && piece >= 8) return 2; // (same coverage as the sieve pipeline: these launches are its fallback)
+            if (ctx->sieve.on && ctx->sieve.stride == 1 && piece >= 8) return 2; // (same coverage as the sieve pipeline: these launches are its fallback)
             return piece >= 31 ? 0 : (piece >= 15 ? 1 : (piece >= 8 ? 2 : (piece >= 6 ? 3 : 4)));
         };
         std::vector<int> idx;
@@ -686,7 +710,7 @@ int build_plan(apm_ctx *ctx) {
             L.kind = APM_KERNEL_BANDED;
             L.key_len = klen;
             L.stride = stride;
-            L.sieved = ctx->sieve.on && stride == 1;
+            L.sieved = ctx->sieve.on && (stride == 1 || ctx->sieve.stride == 8);
             L.qcap = stride == 1 ? 1024 : 512;
             memset(L.lut, 0, sizeof L.lut);
             const int pieces = ctx->k + 1;
@@ -996,7 +1020,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         const int64_t p_hi = std::min<int64_t>(avail, je + ctx->sieve.m_max + band);
         if (p_hi > p_lo && avail_pad >= 16 && avail_pad < ((int64_t)1 << 32) - 4096) {
             // list capacity: 1.5 x the hits expected on uniform codes + 1/256 of the positions, 64 Ki .. 1 Gi entries
-            const double expect = (double)(p_hi - p_lo) * 0.5 * ctx->sieve.rate;
+            const double expect = (double)(p_hi - p_lo) / (ctx->sieve.stride == 8 ? 8.0 : 2.0) * ctx->sieve.rate;
             unsigned long long want = (unsigned long long)(1.5 * expect) + (unsigned long long)(p_hi - p_lo) / 256;
             want = std::min<unsigned long long>(1ull << 30, std::max<unsigned long long>(64ull << 10, want));
             static const long cap_env = getenv("APM_SIEVE_CAP") ? atol(getenv("APM_SIEVE_CAP")) : 0; // test hook: force the overflow fallback
@@ -1021,6 +1045,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             sv.nchunks = (p_hi - p_lo + 1023) / 1024;
             sv.bitmap = reinterpret_cast<const uint4 *>(ds.d_sieve_bmp);
             sv.code_shift = ctx->sieve.code_shift;
+            sv.stride = ctx->sieve.stride;
             sv.cand = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ds.d_cand) + hdr);
             sv.shard_cnt = ds.d_cand + 8;
             sv.shard_cap = ds.cand_cap / APM_CAND_SHARDS;
@@ -1066,6 +1091,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 va.k = ctx->k;
                 va.band = band;
                 va.code_shift = ctx->sieve.code_shift;
+                va.stride = ctx->sieve.stride;
                 va.cand = sv.cand;
                 va.shard_cnt = sv.shard_cnt;
                 va.shard_cap = sv.shard_cap;
@@ -1842,6 +1868,7 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     const std::string n = name;
     if (n == "sieve_on") { *value = ctx->sieve.on ? 1 : 0; return APM_OK; }
     if (n == "sieve_rate") { *value = ctx->sieve.rate; return APM_OK; }
+    if (n == "sieve_stride") { *value = ctx->sieve.on ? (double)ctx->sieve.stride : 0.0; return APM_OK; }
     if (n == "sieve_capacity") { *value = (double)ds.cand_cap; return APM_OK; }
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }
     if (n == "verify_image_bytes") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].image.size(); return APM_OK; }

@@ -21,13 +21,16 @@ struct ApmSieve2Args {
     int64_t avail_pad;          /* bytes readable from text (multiple of 16), < 2^32 */
     int64_t tile0;              /* first scanned relative position (multiple of 16) */
     int64_t nchunks;            /* 1 KiB chunks */
-    const uint4 *bitmap;        /* 32 KiB */
+    const uint4 *bitmap;        /* 32 KiB (stride 8: the first 8 KiB, a bitmap over the 16-bit code words of 8-byte blocks:
+                                   dword x & 2047, bit x >> 11) */
     int code_shift;
+    int stride;                 /* 1: every position (two per lookup, see above); 8: sampled -- the keys' pieces are >= 15 bytes
+                                   long, so each contains an 8-byte block at a multiple of 8: one lookup per 8 text bytes */
     /* candidate list: relative position >> 1, 32 bits each, in APM_CAND_SHARDS regions of shard_cap entries.  A
        workgroup appends to region blockIdx & (SHARDS-1) through that region's own counter (128 bytes apart: one
        shared counter would serialise the appends, ~88 per microsecond chip-wide).  A region that runs full raises
        *cand_n above cand_cap: the verify launches then do nothing and the guarded fallback launches scan. */
-    uint32_t *cand;
+    uint32_t *cand;                /* (stride 8: relative position >> 3) */
     unsigned long long *shard_cnt; /* counter of shard s at shard_cnt[16 * s] */
     unsigned long long shard_cap;
     unsigned long long *cand_n;
@@ -61,6 +64,9 @@ struct ApmVerifyArgs {
     const ApmPatDesc *pats;     /* index = counts[] slot */
     unsigned long long *counts;
     int n_pats, nk, k, band, code_shift;
+    int stride;                 /* as the sieve's: 1 = list entries are position >> 1 and both parities are tried; 8 = entries are
+                                   position >> 3, the key list entries carry the block's offset r inside its piece (bits 11..13 of
+                                   the 15-bit payload, key id in bits 0..10) and the piece is tested at position - r */
     const uint32_t *cand;       /* see ApmSieve2Args */
     const unsigned long long *shard_cnt;
     unsigned long long shard_cap;

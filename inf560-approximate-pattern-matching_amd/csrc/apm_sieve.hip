@@ -133,6 +133,91 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSiev
     if (qcount) spill();
 }
 
+// Sampled form (stride 8): every key piece is >= 15 bytes long and therefore contains an 8-byte block that starts at a
+// multiple of 8 in the text; one lookup per 8 text bytes in an 8 KiB bitmap over the blocks' 16-bit code words.  No
+// bytes beyond the lane's 16 are needed.  ~25 VALU instructions per KiB: the pass is bound by HBM alone.
+__global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve8_kernel(ApmSieve2Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= a.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
+        apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
+        return;
+    }
+    for (int i = tid; i < 512; i += APM_SIEVE2_BLOCK) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
+    __syncthreads();
+    const int64_t W = (int64_t)a.n_main_blocks * (APM_SIEVE2_BLOCK / 64);
+    const int64_t nch = a.nchunks;
+    auto load_chunk = [&](int64_t cc, u32x4 &r) __attribute__((always_inline)) {
+        const int64_t g = a.tile0 + cc * 1024;
+        const int64_t lim = cc < nch ? a.avail_pad - g : 0;
+        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1024 ? 1024u : (uint32_t)lim);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+    };
+    const uint32_t cs = (uint32_t)a.code_shift;
+    auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
+    auto hit_bits = [&](const u32x4 &v, int64_t cc) __attribute__((always_inline)) { // bit t = block at byte 8 t of the lane
+        const uint32_t slo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+        const uint32_t w0 = *(const apm_lds_u32 *)(uintptr_t)((slo << 2) & 0x1ffcu), w1 = *(const apm_lds_u32 *)(uintptr_t)((slo >> 14) & 0x1ffcu);
+        uint32_t hits = ((w0 >> ((slo >> 11) & 31u)) & 1u) | (((w1 >> (slo >> 27)) & 1u) << 1);
+#ifdef APM_MEASURE
+        if (APM_SKIP(a, 1)) hits = 0;
+#endif
+        return cc < nch ? hits : 0u;
+    };
+    uint32_t *s_q = reinterpret_cast<uint32_t *>(smem + 8192) + wv * APM_SIEVE2_QUEUE;
+    uint32_t qcount = 0; // wave-uniform
+    const uint32_t shard = blockIdx.x & (APM_CAND_SHARDS - 1);
+    unsigned long long *const scnt = a.shard_cnt + 16u * shard;
+    uint32_t *const sbase = a.cand + (size_t)shard * (size_t)a.shard_cap;
+    auto spill = [&]() __attribute__((always_inline)) {
+        unsigned long long base = 0;
+        if (lane == 0) {
+            base = atomicAdd(scnt, (unsigned long long)qcount);
+            if (base + qcount > a.shard_cap) atomicMax(a.cand_n, a.cand_cap + 1ull); // region full: flag the overflow
+        }
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
+        for (uint32_t i = (uint32_t)lane; i < qcount; i += 64)
+            if (b + i < a.shard_cap) sbase[b + i] = s_q[i];
+        qcount = 0;
+    };
+    auto push_hits = [&](uint32_t hits, int64_t cc) __attribute__((always_inline)) {
+        const uint32_t eighth = (uint32_t)((a.tile0 + cc * 1024) >> 3) + 2u * (uint32_t)lane; // (relative position of the lane's byte 0) / 8
+        while (__builtin_amdgcn_ballot_w64(hits != 0)) { // <= 2 rounds
+            const bool has = hits != 0;
+            const uint32_t t = has ? (uint32_t)__builtin_ctz(hits) : 0u;
+            hits &= hits - 1u;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (has) s_q[idx] = eighth + t;
+            qcount += (uint32_t)__builtin_popcountll(mask);
+            if (qcount >= (uint32_t)(APM_SIEVE2_QUEUE - 64)) spill();
+        }
+    };
+    int64_t c = ((int64_t)blockIdx.x * (APM_SIEVE2_BLOCK / 64) + wv) * 4; // four neighbouring chunks per wave
+    u32x4 r0, r1, r2, r3;
+    load_chunk(c, r0);
+    load_chunk(c + 1, r1);
+    load_chunk(c + 2, r2);
+    load_chunk(c + 3, r3);
+    for (; c < nch; c += 4 * W) {
+        uint32_t h0, h1, h2, h3;
+        { const u32x4 v = r0; load_chunk(c + 4 * W, r0); h0 = hit_bits(v, c); }
+        { const u32x4 v = r1; load_chunk(c + 4 * W + 1, r1); h1 = hit_bits(v, c + 1); }
+        { const u32x4 v = r2; load_chunk(c + 4 * W + 2, r2); h2 = hit_bits(v, c + 2); }
+        { const u32x4 v = r3; load_chunk(c + 4 * W + 3, r3); h3 = hit_bits(v, c + 3); }
+        if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j);
+        }
+    }
+    if (qcount) spill();
+}
+
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
     if (a.nchunks <= 0) return hipSuccess;
     const size_t lds = 32768 + (size_t)(APM_SIEVE2_BLOCK / 64) * APM_SIEVE2_QUEUE * 4;
@@ -145,6 +230,9 @@ hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
 #endif
     void *kargs[] = {&args};
+    if (a.stride == 8)
+        return hipLaunchKernel((const void *)apm_sieve8_kernel, dim3((unsigned)(nb + a.n_tail)), dim3(APM_SIEVE2_BLOCK), kargs,
+                               8192 + (size_t)(APM_SIEVE2_BLOCK / 64) * APM_SIEVE2_QUEUE * 4, s);
     return hipLaunchKernel((const void *)apm_sieve2_kernel, dim3((unsigned)(nb + a.n_tail)), dim3(APM_SIEVE2_BLOCK), kargs, lds, s);
 }
 
@@ -175,7 +263,8 @@ __host__ __device__ constexpr int apm_verify_scap(int band) { return ((64 + 2 * 
 
 // THREADS = 256 or 512: the bigger workgroup shares one LDS image among eight waves -- more waves per CU when the
 // image (many keys) limits the workgroups per CU
-template <int BAND, int THREADS>
+// SAMPLED: the list comes from the stride-8 sieve (see ApmVerifyArgs::stride)
+template <int BAND, int THREADS, bool SAMPLED>
 __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -416,11 +505,13 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
     bool done = false, active = false, have = false;
     uint32_t p = 0, str = 0, s = 0, pend = 0;
     uint32_t cur = 0, nxt = 0; // current key id | 0x8000 when it is the last of its list; index of the next slot
-    Win win, win_n;
+    Win win, win_n, wk; // text at the candidate position (this / the next batch); SAMPLED: at the piece the key in hand implies
+    constexpr uint32_t PSH = SAMPLED ? 3u : 1u;    // list entry -> relative position
+    constexpr uint32_t KBITS = SAMPLED ? 11u : 15u; // key id bits of a key-list payload; above them the block's offset in its piece
     uint32_t q_n, q_nn;
     bool have_n, have_nn;
     bool ex_n = next_cand(q_n, have_n);
-    load_win((q_n << 1) & ~3u, win_n);
+    load_win((q_n << PSH) & ~3u, win_n);
     bool ex_nn = next_cand(q_nn, have_nn);
     for (;;) {
         if (n_surv >= FLUSH_AT || (done && n_surv)) {
@@ -450,16 +541,21 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
             if (e & 0x8000u) cur = e;
             else { cur = s_slots[e]; nxt = e + 1u; }
             active = true;
+            if constexpr (SAMPLED) { // the block at p lies r bytes inside its piece: the unit's position is p - r
+                s = p - ((cur & 0x7fffu) >> KBITS);
+                if (s > p) s = 0xffffffffu; // (in front of the shard: the pre-check's position test rejects it)
+                load_win(s & ~3u, wk);
+            }
         }
         if (!__builtin_amdgcn_ballot_w64(active)) { // this batch is exhausted: rotate the pipeline
             if (!ex_n) { done = true; continue; }
-            p = q_n << 1; // even relative position
+            p = q_n << PSH; // relative position (even / a multiple of 8)
             have = have_n;
             win = win_n;
             ex_n = ex_nn;
             q_n = q_nn;
             have_n = have_nn;
-            load_win((q_n << 1) & ~3u, win_n);
+            load_win((q_n << PSH) & ~3u, win_n);
             ex_nn = next_cand(q_nn, have_nn);
             // code words of the 8-byte windows at p and p + 1 (16 bits each) out of the 12 bytes from p on
             str = 0;
@@ -469,14 +565,15 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
                 str |= apm_udot4((b4 >> cs) & 0x03030303u, 0x40100401u) << (8 * i);
             }
             const uint32_t x0 = str & 0xffffu, x1 = (str >> 2) & 0xffffu;
-            pend = have ? (((s_bmp[x0 & 2047u] >> (x0 >> 11)) & 1u) | (((s_bmp[x1 & 2047u] >> (x1 >> 11)) & 1u) << 1)) : 0u;
+            pend = have ? (((s_bmp[x0 & 2047u] >> (x0 >> 11)) & 1u) | (SAMPLED ? 0u : (((s_bmp[x1 & 2047u] >> (x1 >> 11)) & 1u) << 1))) : 0u;
 #ifdef APM_MEASURE
             if (APM_SKIP(a, 8)) pend = 0;
 #endif
             continue;
         }
         bool ok = false;
-        if (active) ok = stage1(cur & 0x7fffu, s, win);
+        constexpr uint32_t KMASK = (1u << KBITS) - 1u;
+        if (active) ok = stage1(cur & KMASK, s, SAMPLED ? wk : win);
 #ifdef APM_MEASURE
         if (APM_SKIP(a, 16)) ok = false;
 #endif
@@ -486,12 +583,19 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
 #endif
         if (mask) { // survivors -> the wave's list (ballot + mbcnt, no atomics); at most FLUSH_AT - 1 + 64 entries
             const uint32_t idx = n_surv + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (ok) s_surv[idx] = make_uint2(s, cur & 0x7fffu);
+            if (ok) s_surv[idx] = make_uint2(s, cur & KMASK);
             n_surv += (uint32_t)__builtin_popcountll(mask);
         }
         if (active) {
             if (cur & 0x8000u) active = false;
-            else cur = s_slots[nxt++];
+            else {
+                cur = s_slots[nxt++];
+                if constexpr (SAMPLED) {
+                    s = p - ((cur & 0x7fffu) >> KBITS);
+                    if (s > p) s = 0xffffffffu; // (in front of the shard: the pre-check's position test rejects it)
+                    load_win(s & ~3u, wk);
+                }
+            }
         }
     }
 
@@ -507,16 +611,22 @@ static size_t apm_verify_lds_bytes_t(const ApmVerifyArgs &a, int threads) {
            (size_t)(2 * APM_CAND_SHARDS + 4) * 4 + 16; // image + counts + one survivor list per wave + region tables
 }
 
-static const void *apm_verify_fn(int band, int threads) {
-    switch (band * 2 + (threads == 512 ? 1 : 0)) {
-    case 0: return (const void *)apm_verify_kernel<0, 256>;
-    case 1: return (const void *)apm_verify_kernel<0, 512>;
-    case 2: return (const void *)apm_verify_kernel<1, 256>;
-    case 3: return (const void *)apm_verify_kernel<1, 512>;
-    case 4: return (const void *)apm_verify_kernel<2, 256>;
-    case 5: return (const void *)apm_verify_kernel<2, 512>;
-    case 6: return (const void *)apm_verify_kernel<3, 256>;
-    case 7: return (const void *)apm_verify_kernel<3, 512>;
+static const void *apm_verify_fn(int band, int threads, int stride) {
+    const bool big = threads == 512;
+    if (stride == 8) {
+        switch (band) {
+        case 0: return big ? (const void *)apm_verify_kernel<0, 512, true> : (const void *)apm_verify_kernel<0, 256, true>;
+        case 1: return big ? (const void *)apm_verify_kernel<1, 512, true> : (const void *)apm_verify_kernel<1, 256, true>;
+        case 2: return big ? (const void *)apm_verify_kernel<2, 512, true> : (const void *)apm_verify_kernel<2, 256, true>;
+        case 3: return big ? (const void *)apm_verify_kernel<3, 512, true> : (const void *)apm_verify_kernel<3, 256, true>;
+        default: return nullptr;
+        }
+    }
+    switch (band) {
+    case 0: return big ? (const void *)apm_verify_kernel<0, 512, false> : (const void *)apm_verify_kernel<0, 256, false>;
+    case 1: return big ? (const void *)apm_verify_kernel<1, 512, false> : (const void *)apm_verify_kernel<1, 256, false>;
+    case 2: return big ? (const void *)apm_verify_kernel<2, 512, false> : (const void *)apm_verify_kernel<2, 256, false>;
+    case 3: return big ? (const void *)apm_verify_kernel<3, 512, false> : (const void *)apm_verify_kernel<3, 256, false>;
     default: return nullptr;
     }
 }
@@ -527,7 +637,7 @@ int apm_verify_geometry(const ApmVerifyArgs &a, int *threads) {
     *threads = 256;
     for (int t : {256, 512}) {
         int per_cu = 0;
-        const void *fn = apm_verify_fn(a.band, t);
+        const void *fn = apm_verify_fn(a.band, t, a.stride);
         if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, t, apm_verify_lds_bytes_t(a, t)) != hipSuccess || per_cu < 1) {
             (void)hipGetLastError();
             continue;
@@ -544,7 +654,7 @@ int apm_verify_geometry(const ApmVerifyArgs &a, int *threads) {
 
 hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, hipStream_t s) {
     if (a.n_pats <= 0) return hipSuccess;
-    const void *fn = apm_verify_fn(a.band, threads);
+    const void *fn = apm_verify_fn(a.band, threads, a.stride);
     if (!fn) return hipErrorInvalidValue;
     ApmVerifyArgs args = a;
     args.n_blocks = max_blocks < 1 ? 1 : max_blocks; // (list length unknown on the host: a persistent grid strides over it)
