@@ -186,7 +186,8 @@ int apm_get_timing(const apm_ctx *ctx, apm_timing *out);
 int apm_get_launch_times(const apm_ctx *ctx, int max, double *ms, const char **labels);
 /* Named statistics of the plan / the last counting call on device 0 (introspection for benchmarks and DESIGN.md):
  * "sieve_on", "sieve_rate" (expected candidates per even text position), "sieve_capacity" (list entries),
- * "sieve_candidates", "sieve_overflow" (last call; these two synchronise with the stream), "verify_launches",
+ * "sieve_stride", "sieve_fused" (last call used the fused kernel), "sieve_candidates", "sieve_overflow" (last call of the
+ * two-kernel form; these two synchronise with the stream), "verify_launches",
  * "verify_image_bytes", "verify_blocks_per_cu", "verify_threads".  Unknown names: APM_ERR_INVALID. */
 int apm_get_stat(const apm_ctx *ctx, const char *name, double *value);
 /* Kernel variant AUTO (or the forced variant) resolves to for pattern i. */

@@ -151,6 +151,7 @@ struct DeviceState {
     std::vector<DevVerify> verify;
     unsigned long long *d_cand = nullptr;      // sieve candidate list: [0] = counter, behind [1]: 32-bit entries (position / 2)
     unsigned long long cand_cap = 0;
+    bool last_fused = false;                   // the last call used the fused form of the pipeline
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
     bool events_recorded = false;
     // per-launch event stamps (apm_get_launch_times): stamp i is recorded right behind scan launch i, so the time
@@ -1012,13 +1013,73 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     if (ctx->timing_on) HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
     // sieve + verify pipeline of the per-position classes (needs 16-byte aligned text and < 4 GiB of it: 32-bit
     // buffer offsets, 32-bit list entries); otherwise the LDS-tile / stream launches below do the whole job
-    bool sieve_run = false;
+    bool sieve_run = false, fused_run = false;
     if (ctx->sieve.on && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0) {
         const int band = ctx->k / 2;
         const int64_t avail_pad = avail + (int64_t)((16u - ((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)avail) & 15u)) & 15u);
         const int64_t p_lo = std::max<int64_t>(0, jb - band) & ~(int64_t)15;
         const int64_t p_hi = std::min<int64_t>(avail, je + ctx->sieve.m_max + band);
         if (p_hi > p_lo && avail_pad >= 16 && avail_pad < ((int64_t)1 << 32) - 4096) {
+            // FUSED form (per-position sets whose image leaves LDS room for sixteen wave buffers): one kernel per verify
+            // group, the text is read once, no candidate list and therefore no overflow case and no fallback launches.
+            // Measured SLOWER than the two-kernel pipeline on MI355X (cfg3 0.68 vs 0.50 ms, cfg5 0.82 vs 0.69 ms per GiB:
+            // 4 waves per SIMD instead of 8 and half-empty verification lanes cost more than the second read saves), so
+            // it is opt-in: APM_FUSED=1 (A/B aid; the tests run both forms).
+            static const int fused_env = getenv("APM_FUSED") ? atoi(getenv("APM_FUSED")) : 0;
+            bool fused_ok = fused_env && ctx->sieve.stride == 1;
+            std::vector<ApmFusedArgs> fargs;
+            for (size_t v = 0; fused_ok && v < ctx->sieve.launches.size(); ++v) {
+                VerifyLaunch &V = ctx->sieve.launches[v];
+                ApmFusedArgs fa{};
+                fa.s.text = d_text;
+                fa.s.avail_pad = avail_pad;
+                fa.s.tile0 = p_lo;
+                fa.s.nchunks = (p_hi - p_lo + 1023) / 1024;
+                fa.s.bitmap = reinterpret_cast<const uint4 *>(ds.d_sieve_bmp);
+                fa.s.code_shift = ctx->sieve.code_shift;
+                fa.s.stride = 1;
+                ApmVerifyArgs &va = fa.v;
+                va.text = d_text;
+                va.avail = avail;
+                va.avail_pad = avail_pad;
+                va.jb = jb;
+                va.je = std::min<int64_t>(je, nrel - V.m_min + 1);
+                va.nrel = nrel;
+                va.image = reinterpret_cast<const uint4 *>(ds.verify[v].d_image);
+                va.image_len = (int)V.image.size();
+                va.o_prefix = V.o_prefix;
+                va.o_r2s = V.o_r2s;
+                va.o_slots = V.o_slots;
+                va.o_kext = V.o_kext;
+                va.o_pat = V.o_pat;
+                va.o_masks = V.o_masks;
+                va.kinfo = ds.verify[v].d_kinfo;
+                va.pinfo = reinterpret_cast<const uint2 *>(ds.verify[v].d_pinfo);
+                va.kpart = ds.verify[v].d_kpart;
+                va.pats = ds.verify[v].d_descs;
+                va.counts = d_counts;
+                va.n_pats = (int)V.descs.size();
+                va.nk = (int)V.kinfo.size();
+                va.k = ctx->k;
+                va.band = band;
+                va.code_shift = ctx->sieve.code_shift;
+                va.stride = 1;
+                if (apm_fused_lds_bytes(fa) > (size_t)160 * 1024) fused_ok = false;
+                if (va.je > jb) fargs.push_back(fa);
+            }
+            if (fused_ok) {
+                for (ApmFusedArgs &fa : fargs) {
+                    if (tails_pending) { // the truncated tail windows ride as extra workgroups beside the scan
+                        fa.s.n_tail = (int)ctx->stails.descs.size();
+                        fa.s.tail = ta;
+                        tails_pending = false;
+                    }
+                    HIP_TRY(ctx, apm_launch_fused(fa, ds.n_cu, ds.stream));
+                    { const int nrc = note_launch(ctx, ds, "fused"); if (nrc) return nrc; }
+                }
+                fused_run = true;
+            }
+            if (!fused_run) {
             // list capacity: 1.5 x the hits expected on uniform codes + 1/256 of the positions, 64 Ki .. 1 Gi entries
             const double expect = (double)(p_hi - p_lo) / (ctx->sieve.stride == 8 ? 8.0 : 2.0) * ctx->sieve.rate;
             unsigned long long want = (unsigned long long)(1.5 * expect) + (unsigned long long)(p_hi - p_lo) / 256;
@@ -1105,6 +1166,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 { const int nrc = note_launch(ctx, ds, "verify"); if (nrc) return nrc; }
             }
             sieve_run = true;
+            }
         }
     }
     for (size_t t = 0; t < ctx->tiled.size(); ++t) {
@@ -1112,6 +1174,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         const int64_t je_l = std::min<int64_t>(je, nrel - L.m_min + 1);
         if (je_l <= jb) continue;
         if (L.kind == APM_KERNEL_BANDED) {
+            if (fused_run && L.sieved) continue; // decided inside the fused launch; nothing can overflow there
             ApmFilterArgs f{};
             f.text = d_text;
             f.avail = avail;
@@ -1231,6 +1294,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         else HIP_TRY(ctx, apm_launch_wavefront(a, ds.stream));
         { const int nrc = note_launch(ctx, ds, (L.kind == APM_KERNEL_BITPAR ? "bitpar" : "wavefront")); if (nrc) return nrc; }
     }
+    ds.last_fused = fused_run;
     if (sieve_run) { // the side stream's launches belong to this call
         HIP_TRY(ctx, hipEventRecord(ds.ev_join, ds.side_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ds.stream, ds.ev_join, 0));
@@ -1868,6 +1932,7 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     const std::string n = name;
     if (n == "sieve_on") { *value = ctx->sieve.on ? 1 : 0; return APM_OK; }
     if (n == "sieve_rate") { *value = ctx->sieve.rate; return APM_OK; }
+    if (n == "sieve_fused") { *value = ds.last_fused ? 1 : 0; return APM_OK; }
     if (n == "sieve_stride") { *value = ctx->sieve.on ? (double)ctx->sieve.stride : 0.0; return APM_OK; }
     if (n == "sieve_capacity") { *value = (double)ds.cand_cap; return APM_OK; }
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }

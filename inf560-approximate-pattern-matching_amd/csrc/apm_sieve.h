@@ -79,6 +79,19 @@ struct ApmVerifyArgs {
 #endif
 };
 
+/* FUSED form of the pipeline for per-position key sets whose LDS image leaves room for it (opt-in, APM_FUSED=1:
+ * measured slower than the two kernels, see apm_runtime.hip): ONE kernel, the text is read from HBM once.  A wave stages the 4 KiB it has just sieved (+ 64-byte halos) in its own LDS buffer and verifies
+ * the block's hits out of it on the spot; no candidate list, no second read, no overflow case.  `v` carries the verify
+ * image and records (its list fields are unused). */
+struct ApmFusedArgs {
+    ApmSieve2Args s; /* text, avail_pad, tile0, nchunks, bitmap, code_shift, n_main_blocks, n_tail, tail (list fields unused) */
+    ApmVerifyArgs v;
+};
+#define APM_FUSED_BLOCK 1024
+#define APM_FUSED_TEXT (64 + 4096 + 64) /* per-wave text buffer: front halo | block | back halo */
+hipError_t apm_launch_fused(const ApmFusedArgs &a, int n_cu, hipStream_t s);
+size_t apm_fused_lds_bytes(const ApmFusedArgs &a);
+
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s);
 hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, hipStream_t s);
 int apm_verify_geometry(const ApmVerifyArgs &a, int *threads); /* workgroups per CU; *threads = 256 or 512 */

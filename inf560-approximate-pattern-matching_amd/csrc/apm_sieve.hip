@@ -259,6 +259,184 @@ struct ApmBufText {
     __device__ __forceinline__ int byte(int x) const { return (int)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)(off + (uint32_t)x), 0, 0); }
 };
 
+// six dwords of text from a 4-byte aligned position a0: bytes [a0, a0 + 24)
+struct ApmWin { uint32_t w[6]; };
+
+// The verification core shared by the list-driven verify kernel and the fused kernel: the nomination predicate of a
+// unit, the banded DP of the window it implies, and the stateless dedup of matches.  Text comes through a bounds-checked
+// buffer resource (zeros outside the shard); the predicate takes the loader of its partner's text as a parameter (the
+// fused kernel reads it out of its LDS copy of the block).
+template <int BAND>
+struct ApmVerifyCore {
+    static constexpr int NSH = 2 * BAND + 1;
+    static constexpr bool PAIRS = BAND >= 1;
+    const ApmVerifyArgs &a;
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t avail;
+    const uint32_t *s_kext;
+    const uint4 *s_masks;
+    const uint8_t *s_pat;
+    uint32_t *s_cnt;
+    int lane;
+
+    __device__ __forceinline__ void load_global(uint32_t a0, ApmWin &o) const {
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a0, 0, 0);
+        const v2u32 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(a0 + 16u), 0, 0);
+        o.w[0] = lo.x; o.w[1] = lo.y; o.w[2] = lo.z; o.w[3] = lo.w; o.w[4] = hi.x; o.w[5] = hi.y;
+    }
+    __device__ __forceinline__ int gbyte(uint32_t pos) const { // (slow paths only)
+        return (int)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)pos, 0, 0);
+    }
+
+    // ---- the nomination predicate: key `kid` (one pigeonhole piece) at text position s --------------------
+    // piece intact at s, entirely inside the valid text, and (k >= 2) its partner of the pair pre-check within one
+    // edit (see apm_kernels.hip, "hierarchical verification").  `win` = the six text dwords at s & ~3.
+    // ONE definition for the candidates of the list and for the dedup's "earlier nominator" test.
+    template <typename LoadWin>
+    __device__ __forceinline__ bool stage1(uint32_t kid, uint32_t s, const ApmWin &win, LoadWin &&load_win) const {
+        typedef unsigned long long u64;
+        const uint32_t kx = s_kext[kid];
+        const int at = (int)(kx & 0xffffu), len = (int)((kx >> 16) & 0xffu), n = (int)((kx >> 24) & 31u), side = (int)(kx >> 29);
+        if ((u64)s + (u64)len > (u64)avail) return false;
+        const uint32_t sh = s & 3u;
+        uint32_t A[4], B[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A[i] = __builtin_amdgcn_alignbyte(win.w[i + 1], win.w[i], sh); // text bytes [s, s+16)
+        apm_lds_dwords<4>(s_pat, at, B);
+        const uint4 mk = s_masks[len < 16 ? len : 16]; // 0xff for the first min(len, 16) bytes
+        if ((((A[0] ^ B[0]) & mk.x) | ((A[1] ^ B[1]) & mk.y) | ((A[2] ^ B[2]) & mk.z) | ((A[3] ^ B[3]) & mk.w)) != 0u) return false; // the exact part is not intact
+        for (int x = 16; x < len; ++x)       // (pieces beyond 16 bytes: patterns with long pieces in this class)
+            if (gbyte(s + (uint32_t)x) != (int)s_pat[at + x]) return false;
+        if (!PAIRS || side == 0) return true; // no pre-check (k <= 1) / unpaired last piece (even k)
+        if (n == 31) { // partner longer than 16 bytes: byte loops (definition of the core, apm_ext_fwd / apm_ext_bwd)
+            const uint32_t kp = a.kpart[kid];
+            const int poff = (int)(a.pinfo[a.kinfo[kid] & 0xfffu].x & 0xffffu), ap = (int)(kp & 0xffffu), nn = (int)(kp >> 16), ap1 = ap + nn;
+            const bool fwd = side == 1;
+            auto T = [&](int i) { return fwd ? gbyte(s + (uint32_t)len + (uint32_t)i) : gbyte(s - 1u - (uint32_t)i); };      // text, read away from the exact part
+            auto P = [&](int i) { return fwd ? (int)s_pat[poff + ap + i] : (int)s_pat[poff + ap1 - 1 - i]; };                // partner, same direction
+            int i = 0;
+            while (i < nn && T(i) == P(i)) ++i;
+            if (i >= nn - 1) return true;
+            bool ok = true;
+            for (int j = i + 1; j < nn && ok; ++j) ok = T(j) == P(j);
+            if (ok) return true;
+            ok = true;
+            for (int j = i + 1; j < nn && ok; ++j) ok = T(j - 1) == P(j);
+            if (ok) return true;
+            ok = true;
+            for (int j = i; j < nn && ok; ++j) ok = T(j + 1) == P(j);
+            return ok;
+        }
+        uint32_t P[4], T[5];
+        ApmWin tw;
+        if (side == 1) { // partner behind the piece: text read forward from the end of the piece
+            const uint32_t tp = s + (uint32_t)len;
+            if (len == 0) tw = win; // (a pair of short pieces as one unit: its text starts at s itself)
+            else load_win(tp & ~3u, tw);
+            apm_lds_dwords<4>(s_pat, at + len, P);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) T[i] = __builtin_amdgcn_alignbyte(tw.w[i + 1], tw.w[i], tp & 3u);
+        } else { // partner in front of it: both strings byte-reversed, text = the 20 bytes in front of s
+            uint32_t Q[4], Wd[5];
+            apm_lds_dwords<4>(s_pat, at - 16, Q);
+            if (s >= 20u) {
+                const uint32_t tp = s - 20u;
+                load_win(tp & ~3u, tw);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Wd[i] = __builtin_amdgcn_alignbyte(tw.w[i + 1], tw.w[i], tp & 3u);
+            } else { // the first 20 positions of the shard: bytes in front of text[0] do not exist and read as zero
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Wd[i] = 0u;
+                for (int i = 20 - (int)s; i < 20; ++i) {
+                    const uint32_t b = (uint32_t)gbyte(s - 20u + (uint32_t)i);
+#pragma unroll
+                    for (int d = 0; d < 5; ++d)
+                        if ((i >> 2) == d) Wd[d] |= b << (8 * (i & 3));
+                }
+            }
+#pragma unroll
+            for (int z = 0; z < 4; ++z) P[z] = apm_bswap(Q[3 - z]);
+#pragma unroll
+            for (int z = 0; z < 5; ++z) T[z] = apm_bswap(Wd[4 - z]);
+        }
+        // necessary first: the partner's first four bytes within one edit (a prefix of an alignment with <= 1 edit has
+        // <= 1 edit): nonzero-byte masks of P ^ T under the three alignments, 4 bits each; rejects ~9 of 10 random texts
+        if (n >= 4) {
+            auto nz4 = [](uint32_t x) { return apm_udot4((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7 & 0x01010101u, 0x08040201u); };
+            const uint32_t z0 = nz4(P[0] ^ T[0]);
+            if (z0 & (z0 - 1u)) { // two or more mismatching bytes under the substitution alignment
+                const uint32_t i = (uint32_t)__builtin_ctz(z0); // first mismatching byte: 0..2
+                const uint32_t z1 = nz4(P[0] ^ (T[0] << 8));                                  // pattern byte i has no text counterpart
+                const uint32_t z2 = nz4(P[0] ^ __builtin_amdgcn_alignbyte(T[1], T[0], 1u));   // one extra text byte before pattern byte i
+                if (((z1 >> (i + 1u)) != 0u) && ((z2 >> i) != 0u)) return false;
+            }
+        }
+        return apm_ext1_core16(P, T, n);
+    }
+
+
+    // ---- banded DP of the window a nomination (unit kid at text position s) implies under shift dl ----
+    // on a match: wpat = pattern slot, wj = window start, word = rank of (unit, shift) among the window's nominators
+    __device__ __forceinline__ bool dp_match(uint32_t kid, uint32_t s, int dl, uint32_t &wpat, uint32_t &wj, uint32_t &word) const {
+        const uint32_t ki = a.kinfo[kid];
+        const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kunit = (int)((ki >> 21) & 7u);
+        const uint2 pinf = a.pinfo[kpat];
+        const int poff = (int)(pinf.x & 0xffffu), m = (int)(pinf.x >> 16);
+        const int64_t je_p = min(a.je, a.nrel - m + 1);
+        const int64_t j = (int64_t)s - koff - dl; // candidate window start
+        if (j < a.jb || j >= je_p) return false;
+        wpat = (uint32_t)kpat;
+        wj = (uint32_t)j;
+        word = (uint32_t)(kunit * NSH + dl + BAND);
+#ifdef APM_MEASURE
+        atomicAdd(&a.stats[2], 1ull);
+#endif
+        return apm_banded_verify<BAND>(ApmBufText{rs, (uint32_t)j}, s_pat, poff, m, a.k);
+    }
+
+    // ---- stateless dedup: a matching window counts only from its FIRST true (unit, shift) nominator.  Matches are
+    // rare but come in bursts (an occurrence is nominated by every intact unit, its neighbour windows match too, and
+    // they all sit in one wave).  Among the matches of a round a window is kept by its smallest (unit, shift) only;
+    // what is left is resolved by the whole wave, one match at a time, one lane per earlier (unit, shift): up to
+    // 8 x NSH predicate evaluations with their own text fetches, side by side. ----
+    __device__ __forceinline__ void count_matches(bool hit, uint32_t wpat, uint32_t wj, uint32_t word) const {
+        for (unsigned long long m2 = __builtin_amdgcn_ballot_w64(hit); m2; m2 &= m2 - 1ull) {
+            const int src = __builtin_ctzll(m2);
+            const uint32_t bpat = (uint32_t)__builtin_amdgcn_readlane((int)wpat, src), bj = (uint32_t)__builtin_amdgcn_readlane((int)wj, src);
+            const uint32_t bord = (uint32_t)__builtin_amdgcn_readlane((int)word, src);
+            if (hit && wpat == bpat && wj == bj && word > bord) hit = false;
+        }
+        unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+        while (hm) {
+            const int src = __builtin_ctzll(hm);
+            hm &= hm - 1ull;
+            const uint32_t bpat = (uint32_t)__builtin_amdgcn_readlane((int)wpat, src), bj = (uint32_t)__builtin_amdgcn_readlane((int)wj, src);
+            const int n_before = __builtin_amdgcn_readlane((int)word, src); // (unit, shift) pairs in front of this one: < 64
+            const uint32_t kid0 = a.pinfo[bpat].y; // the pattern's first unit
+            bool earlier = false;
+#ifdef APM_MEASURE
+            if (APM_SKIP(a, 32)) continue;
+#endif
+            if (lane < n_before) {
+                const int qq = lane / NSH, dd = lane % NSH - BAND;
+                const int64_t o = (int64_t)bj + (int)((a.kinfo[kid0 + (uint32_t)qq] >> 12) & 0x1ffu) + dd; // the unit's text position under shift dd
+                if (o >= 0) {
+                    ApmWin w2;
+                    load_global((uint32_t)o & ~3u, w2);
+                    earlier = stage1(kid0 + (uint32_t)qq, (uint32_t)o, w2, [&](uint32_t a0, ApmWin &o2) { load_global(a0, o2); });
+                }
+            }
+            if (!__builtin_amdgcn_ballot_w64(earlier) && lane == 0) {
+                atomicAdd(&s_cnt[bpat], 1u);
+#ifdef APM_MEASURE
+                atomicAdd(&a.stats[3], 1ull);
+#endif
+            }
+        }
+    }
+
+};
+
 __host__ __device__ constexpr int apm_verify_scap(int band) { return ((64 + 2 * band) / (2 * band + 1) + 63 + 7) & ~7; }
 
 // THREADS = 256 or 512: the bigger workgroup shares one LDS image among eight waves -- more waves per CU when the
@@ -271,7 +449,6 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (*a.cand_n > a.cand_cap) return; // the list overflowed: the guarded fallback launches scan instead
     constexpr int NSH = 2 * BAND + 1;
-    constexpr bool PAIRS = BAND >= 1;
     constexpr uint32_t FLUSH_AT = (64 + NSH - 1) / NSH; // the DP pass runs once it fills a wave: (survivor, shift) items
     constexpr int SCAP = apm_verify_scap(BAND);         // capacity of a wave's survivor list: FLUSH_AT - 1 + one round of 64
     uint8_t *s_img = smem;
@@ -321,160 +498,9 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
     const uint32_t avail = (uint32_t)a.avail;
     const uint32_t cs = (uint32_t)a.code_shift;
 
-    // six dwords of text from the 4-byte aligned position a0: bytes [a0, a0 + 24)
-    struct Win { uint32_t w[6]; };
-    auto load_win = [&](uint32_t a0, Win &o) __attribute__((always_inline)) {
-        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a0, 0, 0);
-        const v2u32 hi = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(a0 + 16u), 0, 0);
-        o.w[0] = lo.x; o.w[1] = lo.y; o.w[2] = lo.z; o.w[3] = lo.w; o.w[4] = hi.x; o.w[5] = hi.y;
-    };
-    auto gbyte = [&](uint32_t pos) __attribute__((always_inline)) { // (slow paths only)
-        return (int)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)pos, 0, 0);
-    };
-
-    // ---- the nomination predicate: key `kid` (one pigeonhole piece) at text position s --------------------
-    // piece intact at s, entirely inside the valid text, and (k >= 2) its partner of the pair pre-check within one
-    // edit (see apm_kernels.hip, "hierarchical verification").  `win` = the six text dwords at s & ~3.
-    // ONE definition for the candidates of the list and for the dedup's "earlier nominator" test.
-    auto stage1 = [&](uint32_t kid, uint32_t s, const Win &win) __attribute__((always_inline)) -> bool {
-        typedef unsigned long long u64;
-        const uint32_t kx = s_kext[kid];
-        const int at = (int)(kx & 0xffffu), len = (int)((kx >> 16) & 0xffu), n = (int)((kx >> 24) & 31u), side = (int)(kx >> 29);
-        if ((u64)s + (u64)len > (u64)avail) return false;
-        const uint32_t sh = s & 3u;
-        uint32_t A[4], B[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) A[i] = __builtin_amdgcn_alignbyte(win.w[i + 1], win.w[i], sh); // text bytes [s, s+16)
-        apm_lds_dwords<4>(s_pat, at, B);
-        const uint4 mk = s_masks[len < 16 ? len : 16]; // 0xff for the first min(len, 16) bytes
-        if ((((A[0] ^ B[0]) & mk.x) | ((A[1] ^ B[1]) & mk.y) | ((A[2] ^ B[2]) & mk.z) | ((A[3] ^ B[3]) & mk.w)) != 0u) return false; // the exact part is not intact
-        for (int x = 16; x < len; ++x)       // (pieces beyond 16 bytes: patterns with long pieces in this class)
-            if (gbyte(s + (uint32_t)x) != (int)s_pat[at + x]) return false;
-        if (!PAIRS || side == 0) return true; // no pre-check (k <= 1) / unpaired last piece (even k)
-        if (n == 31) { // partner longer than 16 bytes: byte loops (definition of the core, apm_ext_fwd / apm_ext_bwd)
-            const uint32_t kp = a.kpart[kid];
-            const int poff = (int)(a.pinfo[a.kinfo[kid] & 0xfffu].x & 0xffffu), ap = (int)(kp & 0xffffu), nn = (int)(kp >> 16), ap1 = ap + nn;
-            const bool fwd = side == 1;
-            auto T = [&](int i) { return fwd ? gbyte(s + (uint32_t)len + (uint32_t)i) : gbyte(s - 1u - (uint32_t)i); };      // text, read away from the exact part
-            auto P = [&](int i) { return fwd ? (int)s_pat[poff + ap + i] : (int)s_pat[poff + ap1 - 1 - i]; };                // partner, same direction
-            int i = 0;
-            while (i < nn && T(i) == P(i)) ++i;
-            if (i >= nn - 1) return true;
-            bool ok = true;
-            for (int j = i + 1; j < nn && ok; ++j) ok = T(j) == P(j);
-            if (ok) return true;
-            ok = true;
-            for (int j = i + 1; j < nn && ok; ++j) ok = T(j - 1) == P(j);
-            if (ok) return true;
-            ok = true;
-            for (int j = i; j < nn && ok; ++j) ok = T(j + 1) == P(j);
-            return ok;
-        }
-        uint32_t P[4], T[5];
-        Win tw;
-        if (side == 1) { // partner behind the piece: text read forward from the end of the piece
-            const uint32_t tp = s + (uint32_t)len;
-            if (len == 0) tw = win; // (a pair of short pieces as one unit: its text starts at s itself)
-            else load_win(tp & ~3u, tw);
-            apm_lds_dwords<4>(s_pat, at + len, P);
-#pragma unroll
-            for (int i = 0; i < 5; ++i) T[i] = __builtin_amdgcn_alignbyte(tw.w[i + 1], tw.w[i], tp & 3u);
-        } else { // partner in front of it: both strings byte-reversed, text = the 20 bytes in front of s
-            uint32_t Q[4], Wd[5];
-            apm_lds_dwords<4>(s_pat, at - 16, Q);
-            if (s >= 20u) {
-                const uint32_t tp = s - 20u;
-                load_win(tp & ~3u, tw);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) Wd[i] = __builtin_amdgcn_alignbyte(tw.w[i + 1], tw.w[i], tp & 3u);
-            } else { // the first 20 positions of the shard: bytes in front of text[0] do not exist and read as zero
-#pragma unroll
-                for (int i = 0; i < 5; ++i) Wd[i] = 0u;
-                for (int i = 20 - (int)s; i < 20; ++i) {
-                    const uint32_t b = (uint32_t)gbyte(s - 20u + (uint32_t)i);
-#pragma unroll
-                    for (int d = 0; d < 5; ++d)
-                        if ((i >> 2) == d) Wd[d] |= b << (8 * (i & 3));
-                }
-            }
-#pragma unroll
-            for (int z = 0; z < 4; ++z) P[z] = apm_bswap(Q[3 - z]);
-#pragma unroll
-            for (int z = 0; z < 5; ++z) T[z] = apm_bswap(Wd[4 - z]);
-        }
-        // necessary first: the partner's first four bytes within one edit (a prefix of an alignment with <= 1 edit has
-        // <= 1 edit): nonzero-byte masks of P ^ T under the three alignments, 4 bits each; rejects ~9 of 10 random texts
-        if (n >= 4) {
-            auto nz4 = [](uint32_t x) { return apm_udot4((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7 & 0x01010101u, 0x08040201u); };
-            const uint32_t z0 = nz4(P[0] ^ T[0]);
-            if (z0 & (z0 - 1u)) { // two or more mismatching bytes under the substitution alignment
-                const uint32_t i = (uint32_t)__builtin_ctz(z0); // first mismatching byte: 0..2
-                const uint32_t z1 = nz4(P[0] ^ (T[0] << 8));                                  // pattern byte i has no text counterpart
-                const uint32_t z2 = nz4(P[0] ^ __builtin_amdgcn_alignbyte(T[1], T[0], 1u));   // one extra text byte before pattern byte i
-                if (((z1 >> (i + 1u)) != 0u) && ((z2 >> i) != 0u)) return false;
-            }
-        }
-        return apm_ext1_core16(P, T, n);
-    };
-
-    // ---- banded DP of the window a nomination (unit kid at text position s) implies under shift dl ----
-    // on a match: wpat = pattern slot, wj = window start, word = rank of (unit, shift) among the window's nominators
-    auto dp_match = [&](uint32_t kid, uint32_t s, int dl, uint32_t &wpat, uint32_t &wj, uint32_t &word) __attribute__((always_inline)) -> bool {
-        const uint32_t ki = a.kinfo[kid];
-        const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kunit = (int)((ki >> 21) & 7u);
-        const uint2 pinf = a.pinfo[kpat];
-        const int poff = (int)(pinf.x & 0xffffu), m = (int)(pinf.x >> 16);
-        const int64_t je_p = min(a.je, a.nrel - m + 1);
-        const int64_t j = (int64_t)s - koff - dl; // candidate window start
-        if (j < a.jb || j >= je_p) return false;
-        wpat = (uint32_t)kpat;
-        wj = (uint32_t)j;
-        word = (uint32_t)(kunit * NSH + dl + BAND);
-#ifdef APM_MEASURE
-        atomicAdd(&a.stats[2], 1ull);
-#endif
-        return apm_banded_verify<BAND>(ApmBufText{rs, (uint32_t)j}, s_pat, poff, m, a.k);
-    };
-    // ---- stateless dedup: a matching window counts only from its FIRST true (unit, shift) nominator.  Matches are
-    // rare but come in bursts (an occurrence is nominated by every intact unit, its neighbour windows match too, and
-    // they all sit in one wave).  Among the matches of a round a window is kept by its smallest (unit, shift) only;
-    // what is left is resolved by the whole wave, one match at a time, one lane per earlier (unit, shift): up to
-    // 8 x NSH predicate evaluations with their own text fetches, side by side. ----
-    auto count_matches = [&](bool hit, uint32_t wpat, uint32_t wj, uint32_t word) __attribute__((always_inline)) {
-        for (unsigned long long m2 = __builtin_amdgcn_ballot_w64(hit); m2; m2 &= m2 - 1ull) {
-            const int src = __builtin_ctzll(m2);
-            const uint32_t bpat = (uint32_t)__builtin_amdgcn_readlane((int)wpat, src), bj = (uint32_t)__builtin_amdgcn_readlane((int)wj, src);
-            const uint32_t bord = (uint32_t)__builtin_amdgcn_readlane((int)word, src);
-            if (hit && wpat == bpat && wj == bj && word > bord) hit = false;
-        }
-        unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
-        while (hm) {
-            const int src = __builtin_ctzll(hm);
-            hm &= hm - 1ull;
-            const uint32_t bpat = (uint32_t)__builtin_amdgcn_readlane((int)wpat, src), bj = (uint32_t)__builtin_amdgcn_readlane((int)wj, src);
-            const int n_before = __builtin_amdgcn_readlane((int)word, src); // (unit, shift) pairs in front of this one: < 64
-            const uint32_t kid0 = a.pinfo[bpat].y; // the pattern's first unit
-            bool earlier = false;
-#ifdef APM_MEASURE
-            if (APM_SKIP(a, 32)) continue;
-#endif
-            if (lane < n_before) {
-                const int qq = lane / NSH, dd = lane % NSH - BAND;
-                const int64_t o = (int64_t)bj + (int)((a.kinfo[kid0 + (uint32_t)qq] >> 12) & 0x1ffu) + dd; // the unit's text position under shift dd
-                if (o >= 0) {
-                    Win w2;
-                    load_win((uint32_t)o & ~3u, w2);
-                    earlier = stage1(kid0 + (uint32_t)qq, (uint32_t)o, w2);
-                }
-            }
-            if (!__builtin_amdgcn_ballot_w64(earlier) && lane == 0) {
-                atomicAdd(&s_cnt[bpat], 1u);
-#ifdef APM_MEASURE
-                atomicAdd(&a.stats[3], 1ull);
-#endif
-            }
-        }
-    };
+    ApmVerifyCore<BAND> core{a, rs, avail, s_kext, s_masks, s_pat, s_cnt, lane};
+    typedef ApmWin Win;
+    auto load_win = [&](uint32_t a0, Win &o) __attribute__((always_inline)) { core.load_global(a0, o); };
 
     // ---- batches of 64 candidates per wave.  One loop, one stage-1 site, one DP site: each trip either runs the
     // DP pass over the wave's survivor list, or moves to the next (batch, parity), or evaluates the predicate once
@@ -521,11 +547,11 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
                 const uint2 e = live ? s_surv[wi / NSH] : make_uint2(0u, 0u);
                 const int dl = (int)(wi % NSH) - BAND;
                 uint32_t wpat = 0, wj = 0, word = 0;
-                bool hit = live && dp_match(e.y, e.x, dl, wpat, wj, word);
+                bool hit = live && core.dp_match(e.y, e.x, dl, wpat, wj, word);
 #ifdef APM_MEASURE
                 if (APM_SKIP(a, 64)) hit = false;
 #endif
-                count_matches(hit, wpat, wj, word);
+                core.count_matches(hit, wpat, wj, word);
             }
             n_surv = 0;
         }
@@ -573,7 +599,7 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
         }
         bool ok = false;
         constexpr uint32_t KMASK = (1u << KBITS) - 1u;
-        if (active) ok = stage1(cur & KMASK, s, SAMPLED ? wk : win);
+        if (active) ok = core.stage1(cur & KMASK, s, SAMPLED ? wk : win, load_win);
 #ifdef APM_MEASURE
         if (APM_SKIP(a, 16)) ok = false;
 #endif
@@ -663,4 +689,228 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
 #endif
     void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)args.n_blocks), dim3((unsigned)threads), kargs, apm_verify_lds_bytes_t(a, threads), s);
+}
+
+// ---------------------------------------------------------------------------
+// FUSED: sieve + verify in one pass (see ApmFusedArgs).  1024-thread workgroups, one per CU: sixteen wave-autonomous
+// scanners share the sieve bitmap and the verify image; each owns a 4 KiB (+ halos) text buffer, a 128-entry hit queue
+// and a survivor list.  LDS: 32 KiB + image + 16 x ~5 KiB.
+// ---------------------------------------------------------------------------
+template <int BAND>
+__global__ __launch_bounds__(APM_FUSED_BLOCK, 4) void apm_fused_kernel(ApmFusedArgs f) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const ApmSieve2Args &a = f.s;
+    const ApmVerifyArgs &va = f.v;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= a.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
+        apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
+        return;
+    }
+    constexpr int NSH = 2 * BAND + 1;
+    constexpr uint32_t FLUSH_AT = (64 + NSH - 1) / NSH;
+    constexpr int SCAP = apm_verify_scap(BAND);
+    constexpr int WAVES = APM_FUSED_BLOCK / 64;
+    uint8_t *s_img = smem + 32768;
+    const uint32_t *s_bmp = reinterpret_cast<const uint32_t *>(s_img);
+    const uint16_t *s_prefix = reinterpret_cast<const uint16_t *>(s_img + va.o_prefix);
+    const uint16_t *s_r2s = reinterpret_cast<const uint16_t *>(s_img + va.o_r2s);
+    const uint16_t *s_slots = reinterpret_cast<const uint16_t *>(s_img + va.o_slots);
+    const uint32_t *s_kext = reinterpret_cast<const uint32_t *>(s_img + va.o_kext);
+    const uint8_t *s_pat = s_img + va.o_pat;
+    const uint4 *s_masks = reinterpret_cast<const uint4 *>(s_img + va.o_masks);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_img + va.image_len);
+    uint8_t *s_wave = reinterpret_cast<uint8_t *>(s_cnt + ((va.n_pats + 3) & ~3)) + (size_t)wv * (APM_FUSED_TEXT + 128 * 2 + SCAP * 8);
+    uint8_t *s_text = s_wave;                                                       // this wave's block: [front halo 64 | 4096 | back halo 64]
+    uint16_t *s_q = reinterpret_cast<uint16_t *>(s_wave + APM_FUSED_TEXT);         // hit queue: (position - block start) / 2
+    uint2 *s_surv = reinterpret_cast<uint2 *>(s_wave + APM_FUSED_TEXT + 128 * 2);  // survivors {position, kid}
+
+    for (int i = tid; i < 2048; i += APM_FUSED_BLOCK) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
+    for (int i = tid; i < (va.image_len >> 4); i += APM_FUSED_BLOCK) reinterpret_cast<uint4 *>(s_img)[i] = va.image[i];
+    for (int i = tid; i < va.n_pats; i += APM_FUSED_BLOCK) s_cnt[i] = 0u;
+    __syncthreads(); // the only workgroup barrier before the final count flush
+
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
+    ApmVerifyCore<BAND> core{va, rs, (uint32_t)va.avail, s_kext, s_masks, s_pat, s_cnt, lane};
+    const int64_t W = (int64_t)a.n_main_blocks * WAVES;
+    const int64_t nch = a.nchunks;
+    const uint32_t cs = (uint32_t)a.code_shift;
+
+    // one load per lane per chunk (+ the 8 bytes behind the lane's 16) through the shard-wide resource: zeros past the end
+    auto load_chunk = [&](int64_t cc, u32x4 &r, v2u32 &e) __attribute__((always_inline)) {
+        const uint32_t g = cc < nch ? (uint32_t)(a.tile0 + cc * 1024) + 16u * (uint32_t)lane : 0xfffffff0u;
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)g, 0, 0);
+        e = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(g + 16u), 0, 0);
+    };
+    // halos of the 4 KiB block at relative position blk: lanes 0..3 the 64 bytes in front, lanes 4..7 the 64 behind
+    auto load_halo = [&](int64_t cc, u32x4 &h) __attribute__((always_inline)) {
+        const uint32_t blk = (uint32_t)(a.tile0 + cc * 1024);
+        const uint32_t g = (cc < nch && lane < 8) ? (lane < 4 ? blk - 64u + 16u * (uint32_t)lane : blk + 4096u + 16u * (uint32_t)(lane - 4)) : 0xfffffff0u;
+        h = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)g, 0, 0); // (blk < 64: wraps to a huge offset -> zeros, as every byte outside the shard)
+    };
+    auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
+    auto hit_bits = [&](const u32x4 &v, const v2u32 &e) __attribute__((always_inline)) { // bits 0..7 = even positions 0, 2, .. 14 of the lane
+        const uint32_t slo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
+        const uint32_t shi = pack4(e.x) | (pack4(e.y) << 8);
+        uint32_t hits = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t y = t ? __builtin_amdgcn_alignbit(shi, slo, 4u * (uint32_t)t - 2u) : (slo << 2);
+            const uint32_t word = *(const apm_lds_u32 *)(uintptr_t)(y & 0x7ffcu);
+            hits = __builtin_amdgcn_alignbit(word >> ((y >> 15) & 31u), hits, 1u);
+        }
+        return hits >> 24;
+    };
+    // six text dwords from the 4-byte aligned relative position a0: out of the wave's LDS block when it holds them
+    uint32_t blk = 0; // relative position of the staged block (wave-uniform)
+    auto load_win = [&](uint32_t a0, ApmWin &o) __attribute__((always_inline)) {
+        const uint32_t d = a0 - (blk - 64u); // offset inside the buffer
+        if (d <= (uint32_t)(APM_FUSED_TEXT - 24)) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(s_text + d);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o.w[i] = q[i];
+        } else {
+            core.load_global(a0, o);
+        }
+    };
+
+    uint32_t n_surv = 0; // wave-uniform
+    auto dp_pass = [&]() __attribute__((always_inline)) {
+        for (uint32_t w0 = 0; w0 < n_surv * NSH; w0 += 64) { // one (survivor, shift) per lane
+            const uint32_t wi = w0 + (uint32_t)lane;
+            const bool live = wi < n_surv * NSH;
+            const uint2 e = live ? s_surv[wi / NSH] : make_uint2(0u, 0u);
+            const int dl = (int)(wi % NSH) - BAND;
+            uint32_t wpat = 0, wj = 0, word = 0;
+            const bool hit = live && core.dp_match(e.y, e.x, dl, wpat, wj, word);
+            core.count_matches(hit, wpat, wj, word);
+        }
+        n_surv = 0;
+    };
+
+    int64_t c = ((int64_t)blockIdx.x * WAVES + wv) * 4; // four neighbouring chunks (one 4 KiB block) per wave and round
+    u32x4 r0, r1, r2, r3, hl;
+    v2u32 e0, e1, e2, e3;
+    load_chunk(c, r0, e0);
+    load_chunk(c + 1, r1, e1);
+    load_chunk(c + 2, r2, e2);
+    load_chunk(c + 3, r3, e3);
+    load_halo(c, hl);
+    for (; c < nch; c += 4 * W) {
+        blk = (uint32_t)(a.tile0 + c * 1024);
+        // stage the block, look its even positions up; the loads of the next block are on their way meanwhile
+        uint32_t hm; // this lane's hits: bit 8 j + t = even position 2 t of the lane's 16 bytes in chunk j
+        {
+            const u32x4 v0 = r0, v1 = r1, v2 = r2, v3 = r3, vh = hl;
+            const v2u32 x0 = e0, x1 = e1, x2 = e2, x3 = e3;
+            load_chunk(c + 4 * W, r0, e0);
+            load_chunk(c + 4 * W + 1, r1, e1);
+            load_chunk(c + 4 * W + 2, r2, e2);
+            load_chunk(c + 4 * W + 3, r3, e3);
+            load_halo(c + 4 * W, hl);
+            u32x4 *tb = reinterpret_cast<u32x4 *>(s_text + 64 + 16 * lane);
+            tb[0] = v0;
+            tb[64] = v1;
+            tb[128] = v2;
+            tb[192] = v3;
+            if (lane < 8) *reinterpret_cast<u32x4 *>(s_text + (lane < 4 ? 16 * lane : 64 + 4096 + 16 * (lane - 4))) = vh;
+            hm = hit_bits(v0, x0) | (hit_bits(v1, x1) << 8) | (hit_bits(v2, x2) << 16) | (hit_bits(v3, x3) << 24);
+            // (chunks past the end read as zeros; a zero block may hit the bitmap, the position test of the pre-check rejects it)
+        }
+        uint32_t qcount = 0; // wave-uniform
+        for (;;) {
+            // refill the queue from the hit masks, one hit per lane and round
+            while (qcount < 64u && __builtin_amdgcn_ballot_w64(hm != 0u)) {
+                const bool has = hm != 0u;
+                const uint32_t t = has ? (uint32_t)__builtin_ctz(hm) : 0u;
+                hm &= hm - 1u;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+                const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (has) s_q[idx] = (uint16_t)((t >> 3) * 512u + 8u * (uint32_t)lane + (t & 7u));
+                qcount += (uint32_t)__builtin_popcountll(mask);
+            }
+            if (qcount == 0u) break;
+            const uint32_t nb = qcount < 64u ? qcount : 64u;
+            const bool have = (uint32_t)lane < nb;
+            const uint32_t p = have ? blk + 2u * (uint32_t)s_q[lane] : 0u; // even relative position
+            if (qcount > 64u) { // keep the rest for the next batch
+                const uint16_t rest = s_q[64 + lane];
+                if ((uint32_t)lane < qcount - 64u) s_q[lane] = rest;
+            }
+            qcount -= nb;
+            // ---- one batch of <= 64 candidates, text out of the wave's LDS block ----
+            ApmWin win;
+            load_win(p & ~3u, win);
+            uint32_t str = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const uint32_t b4 = __builtin_amdgcn_alignbyte(win.w[i + 1], win.w[i], p & 3u);
+                str |= apm_udot4((b4 >> cs) & 0x03030303u, 0x40100401u) << (8 * i);
+            }
+            const uint32_t x0 = str & 0xffffu, x1 = (str >> 2) & 0xffffu;
+            uint32_t pend = have ? (((s_bmp[x0 & 2047u] >> (x0 >> 11)) & 1u) | (((s_bmp[x1 & 2047u] >> (x1 >> 11)) & 1u) << 1)) : 0u;
+            bool active = false;
+            uint32_t s = 0, cur = 0, nxt = 0;
+            for (;;) {
+                if (!active && pend) { // next of the lane's (at most two) hit positions: key list by rank
+                    const uint32_t par = (pend & 1u) ? 0u : 1u;
+                    pend &= pend - 1u;
+                    const uint32_t x = (str >> (2u * par)) & 0xffffu, bit = x >> 11;
+                    const uint32_t word = s_bmp[x & 2047u];
+                    const uint32_t e = s_r2s[(uint32_t)s_prefix[x & 2047u] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))];
+                    s = p + par;
+                    if (e & 0x8000u) cur = e;
+                    else { cur = s_slots[e]; nxt = e + 1u; }
+                    active = true;
+                }
+                if (!__builtin_amdgcn_ballot_w64(active)) break;
+                bool ok = false;
+                if (active) ok = core.stage1(cur & 0x7fffu, s, win, load_win);
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+                if (mask) { // survivors -> the wave's list; at most FLUSH_AT - 1 + 64 entries
+                    const uint32_t idx = n_surv + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (ok) s_surv[idx] = make_uint2(s, cur & 0x7fffu);
+                    n_surv += (uint32_t)__builtin_popcountll(mask);
+                }
+                if (active) {
+                    if (cur & 0x8000u) active = false;
+                    else cur = s_slots[nxt++];
+                }
+                if (n_surv >= FLUSH_AT) dp_pass();
+            }
+        }
+    }
+    if (n_surv) dp_pass();
+
+    __syncthreads();
+    for (int i = tid; i < va.n_pats; i += APM_FUSED_BLOCK) {
+        const uint32_t cnt = s_cnt[i];
+        if (cnt) atomicAdd(&va.counts[va.pats[i].index], (unsigned long long)cnt);
+    }
+}
+
+size_t apm_fused_lds_bytes(const ApmFusedArgs &a) {
+    return 32768 + (size_t)a.v.image_len + (size_t)((a.v.n_pats + 3) & ~3) * 4 +
+           (size_t)(APM_FUSED_BLOCK / 64) * (size_t)(APM_FUSED_TEXT + 128 * 2 + apm_verify_scap(a.v.band) * 8) + 16;
+}
+
+hipError_t apm_launch_fused(const ApmFusedArgs &a, int n_cu, hipStream_t s) {
+    if (a.s.nchunks <= 0 || a.v.n_pats <= 0) return hipSuccess;
+    const void *fn = nullptr;
+    switch (a.v.band) {
+    case 0: fn = (const void *)apm_fused_kernel<0>; break;
+    case 1: fn = (const void *)apm_fused_kernel<1>; break;
+    case 2: fn = (const void *)apm_fused_kernel<2>; break;
+    case 3: fn = (const void *)apm_fused_kernel<3>; break;
+    default: return hipErrorInvalidValue;
+    }
+    const size_t lds = apm_fused_lds_bytes(a);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t want = (a.s.nchunks + 4 * (APM_FUSED_BLOCK / 64) - 1) / (4 * (APM_FUSED_BLOCK / 64));
+    const int64_t nb = want < n_cu ? want : n_cu; // one 1024-thread workgroup per CU
+    ApmFusedArgs args = a;
+    args.s.n_main_blocks = (int)nb;
+    void *kargs[] = {&args};
+    return hipLaunchKernel(fn, dim3((unsigned)(nb + a.s.n_tail)), dim3(APM_FUSED_BLOCK), kargs, lds, s);
 }
