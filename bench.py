@@ -325,7 +325,7 @@ def main():
         if exact_k0 is not None:
             rec["counts_equal_closed_form_k0"] = exact_k0
         if ctx.stat("sieve_on"):
-            rec["sieve"] = {key: ctx.stat(key) for key in ("sieve_rate", "sieve_capacity", "sieve_candidates", "sieve_overflow",
+            rec["sieve"] = {key: ctx.stat(key) for key in ("sieve_rate", "sieve_mask_bytes", "sieve_candidates",
                                                             "sieve_stride", "sieve_fused", "verify_launches", "verify_image_bytes", "verify_blocks_per_cu", "verify_threads")}
 
         # full-DP kernel variants, reported under their own label (cells really evaluated)

@@ -185,10 +185,10 @@ int apm_get_timing(const apm_ctx *ctx, apm_timing *out);
  * number written (>= 0) or a negative apm_status.  Synchronises with the last launch. */
 int apm_get_launch_times(const apm_ctx *ctx, int max, double *ms, const char **labels);
 /* Named statistics of the plan / the last counting call on device 0 (introspection for benchmarks and DESIGN.md):
- * "sieve_on", "sieve_rate" (expected candidates per even text position), "sieve_capacity" (list entries),
- * "sieve_stride", "sieve_fused" (last call used the fused kernel), "sieve_candidates", "sieve_overflow" (last call of the
- * two-kernel form; these two synchronise with the stream), "verify_launches",
- * "verify_image_bytes", "verify_blocks_per_cu", "verify_threads".  Unknown names: APM_ERR_INVALID. */
+ * "sieve_on", "sieve_stride" (1 or 8), "sieve_rate" (expected hits per lookup), "sieve_fused" (last call used the fused
+ * kernel), "sieve_mask_bytes" (hit masks the last call's sieve wrote), "sieve_candidates" (their set bits: runs a popcount
+ * kernel and synchronises with the stream), "verify_launches", "verify_image_bytes", "verify_blocks_per_cu",
+ * "verify_threads".  Unknown names: APM_ERR_INVALID. */
 int apm_get_stat(const apm_ctx *ctx, const char *name, double *value);
 /* Kernel variant AUTO (or the forced variant) resolves to for pattern i. */
 int apm_pattern_kernel(const apm_ctx *ctx, int i);

@@ -34,6 +34,15 @@
 // --------------------------------------------------------------------------
 // internal kernels defined here (tiny)
 // --------------------------------------------------------------------------
+// statistics: number of set bits in the sieve's hit masks
+__global__ void apm_popcount_kernel(const uint32_t *w, unsigned long long n, unsigned long long *sum) {
+    unsigned long long acc = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        acc += (unsigned long long)__popc(w[i]);
+    for (int d = 32; d; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
+}
+
 // k >= m: every window start matches (the DP never exceeds m); one launch adds the window count to all of them
 __global__ void apm_add_const_kernel(unsigned long long *counts, const int *idx, int n, unsigned long long v) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -130,8 +139,6 @@ struct DeviceState {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    hipStream_t side_stream = nullptr;        // the guarded fallback launches of the sieve pipeline run beside the verify launches
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *d_allpat = nullptr;              // every pattern's raw bytes, concatenated
     ApmPatDesc *d_tail_descs = nullptr;       // tails of tiled-kernel patterns with m > 128 (generic kernel)
     ApmPatDesc *d_stail_descs = nullptr;      // tails of tiled-kernel patterns with m <= 128 (tail kernel)
@@ -149,8 +156,10 @@ struct DeviceState {
     hipEvent_t ev_stage[32] = {};             // apm_count_file: staging buffer b copied out (this device's stream)
     uint32_t *d_sieve_bmp = nullptr;           // sieve bitmap (32 KiB)
     std::vector<DevVerify> verify;
-    unsigned long long *d_cand = nullptr;      // sieve candidate list: [0] = counter, behind [1]: 32-bit entries (position / 2)
-    unsigned long long cand_cap = 0;
+    uint32_t *d_masks = nullptr;               // the sieve's hit masks: one dword per lane and 4 KiB block (n / 16 bytes)
+    size_t masks_cap = 0;                      // dwords
+    int64_t last_mask_blocks = 0;              // blocks the last call's sieve wrote (statistics)
+    unsigned long long *d_stats = nullptr;     // 8 counters (statistics kernel; measurement build: verify counters)
     bool last_fused = false;                   // the last call used the fused form of the pipeline
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
     bool events_recorded = false;
@@ -1080,25 +1089,20 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 fused_run = true;
             }
             if (!fused_run) {
-            // list capacity: 1.5 x the hits expected on uniform codes + 1/256 of the positions, 64 Ki .. 1 Gi entries
-            const double expect = (double)(p_hi - p_lo) / (ctx->sieve.stride == 8 ? 8.0 : 2.0) * ctx->sieve.rate;
-            unsigned long long want = (unsigned long long)(1.5 * expect) + (unsigned long long)(p_hi - p_lo) / 256;
-            want = std::min<unsigned long long>(1ull << 30, std::max<unsigned long long>(64ull << 10, want));
-            static const long cap_env = getenv("APM_SIEVE_CAP") ? atol(getenv("APM_SIEVE_CAP")) : 0; // test hook: force the overflow fallback
-            if (cap_env > 0) want = (unsigned long long)cap_env;
-            want = (want + APM_CAND_SHARDS - 1) / APM_CAND_SHARDS * APM_CAND_SHARDS; // equal regions
-            const size_t hdr = 64 + (size_t)APM_CAND_SHARDS * 128; // overflow flag + one counter per region, 128 bytes apart
-            if (ds.cand_cap != want && (ds.cand_cap < want || cap_env > 0)) {
-                if (ds.d_cand) {
+            // hit masks: one dword per lane and 4 KiB block; every one is written by the sieve, nothing to clear
+            const int64_t n_mask_blocks = ((p_hi - p_lo + 1023) / 1024 + 3) / 4;
+            const size_t need = (size_t)n_mask_blocks * 64 + 64;
+            if (ds.masks_cap < need) {
+                if (ds.d_masks) {
                     HIP_TRY(ctx, hipStreamSynchronize(ds.stream)); // (a verify launch of an earlier call may still read it)
-                    HIP_TRY(ctx, hipFree(ds.d_cand));
+                    HIP_TRY(ctx, hipFree(ds.d_masks));
                 }
-                ds.d_cand = nullptr;
-                ds.cand_cap = 0;
-                HIP_TRY(ctx, hipMalloc((void **)&ds.d_cand, hdr + (size_t)want * 4 + 16));
-                ds.cand_cap = want;
+                ds.d_masks = nullptr;
+                ds.masks_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&ds.d_masks, need * 4));
+                ds.masks_cap = need;
             }
-            HIP_TRY(ctx, hipMemsetAsync(ds.d_cand, 0, hdr, ds.stream));
+            ds.last_mask_blocks = n_mask_blocks;
             ApmSieve2Args sv{};
             sv.text = d_text;
             sv.avail_pad = avail_pad;
@@ -1107,11 +1111,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             sv.bitmap = reinterpret_cast<const uint4 *>(ds.d_sieve_bmp);
             sv.code_shift = ctx->sieve.code_shift;
             sv.stride = ctx->sieve.stride;
-            sv.cand = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(ds.d_cand) + hdr);
-            sv.shard_cnt = ds.d_cand + 8;
-            sv.shard_cap = ds.cand_cap / APM_CAND_SHARDS;
-            sv.cand_n = ds.d_cand;
-            sv.cand_cap = ds.cand_cap;
+            sv.masks = ds.d_masks;
             if (tails_pending) { // the truncated tail windows ride as extra workgroups beside the scan
                 sv.n_tail = (int)ctx->stails.descs.size();
                 sv.tail = ta;
@@ -1119,10 +1119,6 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             }
             HIP_TRY(ctx, apm_launch_sieve2(sv, ds.n_cu, ds.stream));
             { const int nrc = note_launch(ctx, ds, "sieve"); if (nrc) return nrc; }
-            // the guarded fallback launches (no-ops unless the list overflowed) go to a side stream behind the sieve and
-            // run beside the verify launches instead of adding their kernel boundaries to the step
-            HIP_TRY(ctx, hipEventRecord(ds.ev_fork, ds.stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ds.side_stream, ds.ev_fork, 0));
             for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
                 VerifyLaunch &V = ctx->sieve.launches[v];
                 const int64_t je_v = std::min<int64_t>(je, nrel - V.m_min + 1);
@@ -1153,13 +1149,13 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 va.band = band;
                 va.code_shift = ctx->sieve.code_shift;
                 va.stride = ctx->sieve.stride;
-                va.cand = sv.cand;
-                va.shard_cnt = sv.shard_cnt;
-                va.shard_cap = sv.shard_cap;
-                va.cand_n = sv.cand_n;
-                va.cand_cap = sv.cand_cap;
+                va.masks = ds.d_masks;
+                va.tile0 = p_lo;
+                va.n_mask_blocks = n_mask_blocks;
 #ifdef APM_MEASURE
-                va.stats = ds.d_cand + 2;
+                if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, 64));
+                HIP_TRY(ctx, hipMemsetAsync(ds.d_stats, 0, 64, ds.stream));
+                va.stats = ds.d_stats;
 #endif
                 if (!V.blocks_per_cu) V.blocks_per_cu = apm_verify_geometry(va, &V.threads);
                 HIP_TRY(ctx, apm_launch_verify(va, V.threads, ds.n_cu * V.blocks_per_cu, ds.stream));
@@ -1174,7 +1170,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         const int64_t je_l = std::min<int64_t>(je, nrel - L.m_min + 1);
         if (je_l <= jb) continue;
         if (L.kind == APM_KERNEL_BANDED) {
-            if (fused_run && L.sieved) continue; // decided inside the fused launch; nothing can overflow there
+            if ((fused_run || sieve_run) && L.sieved) continue; // decided by the sieve pipeline above (it cannot overflow: no fallback)
             ApmFilterArgs f{};
             f.text = d_text;
             f.avail = avail;
@@ -1227,13 +1223,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             // per-position classes stream only when candidates are expected to be rare (verification then
             // reads global text, dense 64-candidate batches); APM_FILTER_STREAM=2 forces, 3 forbids (A/B aid)
             const double hit_rate = (double)L.keys.size() / (double)(1ull << (2 * std::min(L.key_len, 8)));
-            const bool sieved = sieve_run && L.sieved; // covered by the pipeline above: this launch only guards against list overflow
-            if (sieved) {
-                f.cand_n = ds.d_cand;
-                f.cand_cap = ds.cand_cap;
-                f.cand_mode = 2;
-            }
-            const bool stream_ok = L.stride > 1 || (f.band <= 1 && (sieved || stream_env == 2 || (stream_env != 3 && hit_rate < 1.0 / 200.0)));
+            const bool stream_ok = L.stride > 1 || (f.band <= 1 && (stream_env == 2 || (stream_env != 3 && hit_rate < 1.0 / 200.0)));
             if (stream_env && stream_ok && (reinterpret_cast<uintptr_t>(d_text) & 15u) == 0 && f.avail_pad >= 16) {
                 // wave-autonomous streaming kernel over 1 KiB chunks
                 const int64_t p_lo = std::max<int64_t>(0, jb - f.band) & ~(int64_t)15;
@@ -1246,9 +1236,8 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                     f.tail = ta;
                     tails_pending = false;
                 }
-                HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], sieved ? ds.side_stream : ds.stream));
-                if (sieved) ds.launches++;
-                else { const int nrc = note_launch(ctx, ds, "stream"); if (nrc) return nrc; }
+                HIP_TRY(ctx, apm_launch_stream(f, ds.n_cu * L.blocks_per_cu[2], ds.stream));
+                { const int nrc = note_launch(ctx, ds, "stream"); if (nrc) return nrc; }
                 continue;
             }
             if (!ctx->tiled[t].blocks_per_cu[f.use_dma])
@@ -1265,10 +1254,9 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 static const int bpc_env = getenv("APM_BPC_CAP") ? atoi(getenv("APM_BPC_CAP")) : 0;
                 if (bpc_env > 0) bpc = std::min(bpc_env, bpc);
 #endif
-                HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * bpc, sieved ? ds.side_stream : ds.stream));
+                HIP_TRY(ctx, apm_launch_filter(f, ds.n_cu * bpc, ds.stream));
             }
-            if (sieved) ds.launches++;
-            else { const int nrc = note_launch(ctx, ds, "tile"); if (nrc) return nrc; }
+            { const int nrc = note_launch(ctx, ds, "tile"); if (nrc) return nrc; }
             continue;
         }
         ApmScanArgs a{};
@@ -1295,10 +1283,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         { const int nrc = note_launch(ctx, ds, (L.kind == APM_KERNEL_BITPAR ? "bitpar" : "wavefront")); if (nrc) return nrc; }
     }
     ds.last_fused = fused_run;
-    if (sieve_run) { // the side stream's launches belong to this call
-        HIP_TRY(ctx, hipEventRecord(ds.ev_join, ds.side_stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ds.stream, ds.ev_join, 0));
-    }
+    if (!sieve_run) ds.last_mask_blocks = 0;
     int rc = launch_generic_group(ctx, ds, ctx->longs, ds.d_long_descs, 2, d_text, avail, jb, je, nrel, d_counts, sink);
     if (rc) return rc;
     if (ctx->timing_on) HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
@@ -1471,9 +1456,6 @@ int init_device(apm_ctx *ctx, DeviceState &ds, int dev) {
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) ds.n_cu = ncu;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ds.own_stream, hipStreamNonBlocking));
     ds.stream = ds.own_stream;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ds.side_stream, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&ds.ev_join, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreate(&ds.ev_start));
     HIP_TRY(ctx, hipEventCreate(&ds.ev_kstart));
     HIP_TRY(ctx, hipEventCreate(&ds.ev_mstart));
@@ -1606,12 +1588,11 @@ void apm_destroy(apm_ctx *ctx) {
         free_device_plan(ds);
         if (ds.d_scratch) hipFree(ds.d_scratch);
         if (ds.d_text) hipFree(ds.d_text);
-        if (ds.d_cand) hipFree(ds.d_cand);
+        if (ds.d_masks) hipFree(ds.d_masks);
+        if (ds.d_stats) hipFree(ds.d_stats);
         for (hipEvent_t e : ds.ev_stage) if (e) hipEventDestroy(e);
         for (hipEvent_t e : ds.ev_launch) if (e) hipEventDestroy(e);
         for (hipEvent_t e : {ds.ev_start, ds.ev_kstart, ds.ev_mstart, ds.ev_mstop, ds.ev_stop}) if (e) hipEventDestroy(e);
-        if (ds.side_stream) hipStreamSynchronize(ds.side_stream), hipStreamDestroy(ds.side_stream);
-        for (hipEvent_t e : {ds.ev_fork, ds.ev_join}) if (e) hipEventDestroy(e);
         if (ds.own_stream) hipStreamDestroy(ds.own_stream);
     }
     for (int b = 0; b < apm_ctx::N_STAGE; ++b)
@@ -1934,29 +1915,36 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     if (n == "sieve_rate") { *value = ctx->sieve.rate; return APM_OK; }
     if (n == "sieve_fused") { *value = ds.last_fused ? 1 : 0; return APM_OK; }
     if (n == "sieve_stride") { *value = ctx->sieve.on ? (double)ctx->sieve.stride : 0.0; return APM_OK; }
-    if (n == "sieve_capacity") { *value = (double)ds.cand_cap; return APM_OK; }
+    if (n == "sieve_mask_bytes") { *value = (double)ds.last_mask_blocks * 256.0; return APM_OK; }
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }
     if (n == "verify_image_bytes") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].image.size(); return APM_OK; }
     if (n == "verify_blocks_per_cu") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].blocks_per_cu; return APM_OK; }
     if (n == "verify_threads") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].threads; return APM_OK; }
-    if (n == "sieve_candidates" || n == "sieve_overflow" || n.rfind("verify_", 0) == 0) { // of the last call (synchronises with the stream)
-        if (!ds.d_cand) { *value = 0; return APM_OK; }
+    if (n == "sieve_candidates") { // hits of the last call's sieve: popcount over its masks (synchronises with the stream)
+        *value = 0;
+        if (!ds.d_masks || ds.last_mask_blocks <= 0) return APM_OK;
         HIP_TRY(ctx, hipSetDevice(ds.dev));
+        if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, 64));
+        unsigned long long *d_sum = ds.d_stats + 7;
+        HIP_TRY(ctx, hipMemsetAsync(d_sum, 0, 8, ds.stream));
+        hipLaunchKernelGGL(apm_popcount_kernel, dim3(1024), dim3(256), 0, ds.stream, ds.d_masks, (unsigned long long)ds.last_mask_blocks * 64ull, d_sum);
+        unsigned long long h = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, ds.stream));
         HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
-        std::vector<unsigned long long> h(8 + 16 * APM_CAND_SHARDS);
-        HIP_TRY(ctx, hipMemcpy(h.data(), ds.d_cand, h.size() * 8, hipMemcpyDeviceToHost));
-        if (n == "sieve_overflow") { *value = h[0] > ds.cand_cap ? 1 : 0; return APM_OK; }
-#ifdef APM_MEASURE
-        if (n == "verify_prechecks") { *value = (double)h[2]; return APM_OK; }
-        if (n == "verify_survivors") { *value = (double)h[3]; return APM_OK; }
-        if (n == "verify_dp_items") { *value = (double)h[4]; return APM_OK; }
-        if (n == "verify_counted") { *value = (double)h[5]; return APM_OK; }
-#endif
-        double sum = 0;
-        for (int i = 0; i < APM_CAND_SHARDS; ++i) sum += (double)h[8 + 16 * (size_t)i];
-        *value = sum;
+        *value = (double)h;
         return APM_OK;
     }
+#ifdef APM_MEASURE
+    if (n.rfind("verify_", 0) == 0 && ds.d_stats) {
+        HIP_TRY(ctx, hipSetDevice(ds.dev));
+        HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+        unsigned long long h[8] = {};
+        HIP_TRY(ctx, hipMemcpy(h, ds.d_stats, 64, hipMemcpyDeviceToHost));
+        if (n == "verify_survivors") { *value = (double)h[1]; return APM_OK; }
+        if (n == "verify_dp_items") { *value = (double)h[2]; return APM_OK; }
+        if (n == "verify_counted") { *value = (double)h[3]; return APM_OK; }
+    }
+#endif
     return fail(ctx, APM_ERR_INVALID, "unknown statistic '%s'", name);
 }
 

@@ -26,15 +26,12 @@ struct ApmSieve2Args {
     int code_shift;
     int stride;                 /* 1: every position (two per lookup, see above); 8: sampled -- the keys' pieces are >= 15 bytes
                                    long, so each contains an 8-byte block at a multiple of 8: one lookup per 8 text bytes */
-    /* candidate list: relative position >> 1, 32 bits each, in APM_CAND_SHARDS regions of shard_cap entries.  A
-       workgroup appends to region blockIdx & (SHARDS-1) through that region's own counter (128 bytes apart: one
-       shared counter would serialise the appends, ~88 per microsecond chip-wide).  A region that runs full raises
-       *cand_n above cand_cap: the verify launches then do nothing and the guarded fallback launches scan. */
-    uint32_t *cand;                /* (stride 8: relative position >> 3) */
-    unsigned long long *shard_cnt; /* counter of shard s at shard_cnt[16 * s] */
-    unsigned long long shard_cap;
-    unsigned long long *cand_n;
-    unsigned long long cand_cap;
+    /* hit masks, the hand-over to the verify launches: one dword per lane and 4 KiB block of text (block b = the four
+       chunks 4b .. 4b+3 from tile0 on; dword masks[64 b + lane]): bit 8 j + t = the lane's lookup t in chunk j hit, i.e.
+       relative position tile0 + 4096 b + 1024 j + 16 lane + 2 t (stride 8: + 8 t, t < 2).  Every dword of every block is
+       written by exactly one wave with one coalesced store: no queue, no atomics, no capacity, nothing to overflow;
+       n / 16 bytes. */
+    uint32_t *masks;
     int n_main_blocks;          /* set by the launcher: scanning workgroups */
     int n_tail;                 /* extra workgroups, one per pattern with truncated tail windows (they run beside the scan) */
     ApmTailArgs tail;
@@ -42,7 +39,6 @@ struct ApmSieve2Args {
     int skip_mask;
 #endif
 };
-#define APM_CAND_SHARDS 256
 
 struct ApmVerifyArgs {
     const uint8_t *text;        /* 16-byte aligned */
@@ -64,14 +60,12 @@ struct ApmVerifyArgs {
     const ApmPatDesc *pats;     /* index = counts[] slot */
     unsigned long long *counts;
     int n_pats, nk, k, band, code_shift;
-    int stride;                 /* as the sieve's: 1 = list entries are position >> 1 and both parities are tried; 8 = entries are
-                                   position >> 3, the key list entries carry the block's offset r inside its piece (bits 11..13 of
+    int stride;                 /* as the sieve's: 1 = hits are even positions and both parities are tried; 8 = hits are multiples
+                                   of 8, the key list entries carry the block's offset r inside its piece (bits 11..13 of
                                    the 15-bit payload, key id in bits 0..10) and the piece is tested at position - r */
-    const uint32_t *cand;       /* see ApmSieve2Args */
-    const unsigned long long *shard_cnt;
-    unsigned long long shard_cap;
-    const unsigned long long *cand_n;
-    unsigned long long cand_cap;
+    const uint32_t *masks;      /* see ApmSieve2Args */
+    int64_t tile0;              /* relative position of block 0 */
+    int64_t n_mask_blocks;      /* 4 KiB blocks the sieve wrote masks for */
     int n_blocks;               /* set by the launcher */
 #ifdef APM_MEASURE
     int skip_mask;

@@ -8,24 +8,27 @@
  *                       The lane's 24 bytes become a 48-bit string of 2-bit codes (v_dot4_u32_u8 packs four
  *                       codes per instruction); every EVEN position's 18-bit code word (9 bytes) is one lookup in
  *                       a 32 KiB LDS presence bitmap that answers for the position and the odd one behind it.
- *                       Hits leave for a global candidate list through a wave-private LDS queue, one global
- *                       atomic per >= 128 hits.
- *   apm_verify_kernel   list-driven: one candidate per lane, 64 per wave and batch.  Key identification by rank
+ *                       The hit masks of a 4 KiB block (32 bits per lane) leave with one coalesced store.
+ *   apm_verify_kernel   mask-driven: a wave walks its run of blocks, compacts the hits into batches of 64 (one
+ *                       candidate per lane, dense across block borders: the text comes from global memory).  Key identification by rank
  *                       over the exact 16-bit presence bitmap (two dependent LDS reads, no hashing, no tags),
  *                       piece compare + pair pre-check against global text (bounds-checked buffer loads), the
  *                       survivors of a wave are collected and the banded DP + stateless dedup run on dense lanes.
  *
  * Both need a 16-byte aligned text pointer and a shard of < 4 GiB; the runtime falls back to the LDS-tile
- * kernels of apm_kernels.hip otherwise, and (guarded on the device) when the candidate list overflows.
+ * kernels of apm_kernels.hip otherwise.
  */
 #include "apm_device.h"
 #include "apm_sieve.h"
+
+#ifndef APM_VERIFY_PIPE
+#define APM_VERIFY_PIPE 2 /* batches formed ahead of the one in hand (measured: 2 beats 1 by 17 % on cfg3: the window loads of batch b+1 then do not wait for the queue reads that form it) */
+#endif
 
 typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) uint32_t apm_lds_u32; // LDS dword, for constant-base accesses
 
 #define APM_SIEVE2_BLOCK 512
-#define APM_SIEVE2_QUEUE 192 /* queue entries per wave: spilled to the list once it holds >= 128 */
 
 __device__ __forceinline__ uint32_t apm_udot4(uint32_t a, uint32_t b) {
     return __builtin_amdgcn_udot4(a, b, 0u, false); // v_dot4_u32_u8
@@ -78,40 +81,6 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSiev
 #endif
         return cc < nch ? hits : 0u;
     };
-    // hit positions are staged in a wave-private LDS queue (ballot + mbcnt, no atomics) and leave for the
-    // global list 128+ at a time: one global atomic per batch, not per hit
-    uint32_t *s_q = reinterpret_cast<uint32_t *>(smem + 32768) + wv * APM_SIEVE2_QUEUE;
-    uint32_t qcount = 0; // wave-uniform
-    const uint32_t shard = blockIdx.x & (APM_CAND_SHARDS - 1);
-    unsigned long long *const scnt = a.shard_cnt + 16u * shard;
-    uint32_t *const sbase = a.cand + (size_t)shard * (size_t)a.shard_cap;
-    auto spill = [&]() __attribute__((always_inline)) {
-        unsigned long long base = 0;
-        if (lane == 0) {
-            base = atomicAdd(scnt, (unsigned long long)qcount);
-            if (base + qcount > a.shard_cap) atomicMax(a.cand_n, a.cand_cap + 1ull); // region full: flag the overflow
-        }
-        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-        const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
-        for (uint32_t i = (uint32_t)lane; i < qcount; i += 64)
-            if (b + i < a.shard_cap) sbase[b + i] = s_q[i];
-        qcount = 0;
-    };
-    auto push_hits = [&](uint32_t hits, int64_t cc) __attribute__((always_inline)) {
-        const uint32_t half = (uint32_t)((a.tile0 + cc * 1024) >> 1) + 8u * (uint32_t)lane; // (relative position of the lane's byte 0) / 2
-        while (__builtin_amdgcn_ballot_w64(hits != 0)) { // <= 8 rounds of <= 64 positions
-            const bool has = hits != 0;
-            const uint32_t t = has ? (uint32_t)__builtin_ctz(hits) - 24u : 0u;
-            hits &= hits - 1u; // (0 stays 0)
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
-            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (has) s_q[idx] = half + t;
-            qcount += (uint32_t)__builtin_popcountll(mask);
-            if (qcount >= (uint32_t)(APM_SIEVE2_QUEUE - 64)) spill();
-        }
-    };
-
     int64_t c = ((int64_t)blockIdx.x * (APM_SIEVE2_BLOCK / 64) + wv) * 4; // four neighbouring chunks per wave
     u32x4 r0, r1, r2, r3;
     v2u32 e0, e1, e2, e3;
@@ -125,12 +94,9 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSiev
         { const u32x4 v = r1; const v2u32 e = e1; load_chunk(c + 4 * W + 1, r1, e1); h1 = hit_bits(v, e, c + 1); }
         { const u32x4 v = r2; const v2u32 e = e2; load_chunk(c + 4 * W + 2, r2, e2); h2 = hit_bits(v, e, c + 2); }
         { const u32x4 v = r3; const v2u32 e = e3; load_chunk(c + 4 * W + 3, r3, e3); h3 = hit_bits(v, e, c + 3); }
-        if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j);
-        }
+        // the block's hit masks: one coalesced 256-byte store per wave and 4 KiB (see ApmSieve2Args::masks)
+        a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = (h0 >> 24) | ((h1 >> 24) << 8) | ((h2 >> 24) << 16) | (h3 & 0xff000000u);
     }
-    if (qcount) spill();
 }
 
 // Sampled form (stride 8): every key piece is >= 15 bytes long and therefore contains an 8-byte block that starts at a
@@ -167,37 +133,6 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve8_kernel(ApmSiev
 #endif
         return cc < nch ? hits : 0u;
     };
-    uint32_t *s_q = reinterpret_cast<uint32_t *>(smem + 8192) + wv * APM_SIEVE2_QUEUE;
-    uint32_t qcount = 0; // wave-uniform
-    const uint32_t shard = blockIdx.x & (APM_CAND_SHARDS - 1);
-    unsigned long long *const scnt = a.shard_cnt + 16u * shard;
-    uint32_t *const sbase = a.cand + (size_t)shard * (size_t)a.shard_cap;
-    auto spill = [&]() __attribute__((always_inline)) {
-        unsigned long long base = 0;
-        if (lane == 0) {
-            base = atomicAdd(scnt, (unsigned long long)qcount);
-            if (base + qcount > a.shard_cap) atomicMax(a.cand_n, a.cand_cap + 1ull); // region full: flag the overflow
-        }
-        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-        const unsigned long long b = ((unsigned long long)bhi << 32) | blo;
-        for (uint32_t i = (uint32_t)lane; i < qcount; i += 64)
-            if (b + i < a.shard_cap) sbase[b + i] = s_q[i];
-        qcount = 0;
-    };
-    auto push_hits = [&](uint32_t hits, int64_t cc) __attribute__((always_inline)) {
-        const uint32_t eighth = (uint32_t)((a.tile0 + cc * 1024) >> 3) + 2u * (uint32_t)lane; // (relative position of the lane's byte 0) / 8
-        while (__builtin_amdgcn_ballot_w64(hits != 0)) { // <= 2 rounds
-            const bool has = hits != 0;
-            const uint32_t t = has ? (uint32_t)__builtin_ctz(hits) : 0u;
-            hits &= hits - 1u;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
-            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (has) s_q[idx] = eighth + t;
-            qcount += (uint32_t)__builtin_popcountll(mask);
-            if (qcount >= (uint32_t)(APM_SIEVE2_QUEUE - 64)) spill();
-        }
-    };
     int64_t c = ((int64_t)blockIdx.x * (APM_SIEVE2_BLOCK / 64) + wv) * 4; // four neighbouring chunks per wave
     u32x4 r0, r1, r2, r3;
     load_chunk(c, r0);
@@ -210,19 +145,16 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve8_kernel(ApmSiev
         { const u32x4 v = r1; load_chunk(c + 4 * W + 1, r1); h1 = hit_bits(v, c + 1); }
         { const u32x4 v = r2; load_chunk(c + 4 * W + 2, r2); h2 = hit_bits(v, c + 2); }
         { const u32x4 v = r3; load_chunk(c + 4 * W + 3, r3); h3 = hit_bits(v, c + 3); }
-        if (__builtin_amdgcn_ballot_w64((h0 | h1 | h2 | h3) != 0)) {
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) push_hits(j == 0 ? h0 : (j == 1 ? h1 : (j == 2 ? h2 : h3)), c + j);
-        }
+        // the block's hit masks (two lookups per lane and chunk): one coalesced 256-byte store per wave and 4 KiB
+        a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = h0 | (h1 << 8) | (h2 << 16) | (h3 << 24);
     }
-    if (qcount) spill();
 }
 
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
     if (a.nchunks <= 0) return hipSuccess;
-    const size_t lds = 32768 + (size_t)(APM_SIEVE2_BLOCK / 64) * APM_SIEVE2_QUEUE * 4;
+    const size_t lds = 32768;
     const int64_t want = (a.nchunks + 4 * (APM_SIEVE2_BLOCK / 64) - 1) / (4 * (APM_SIEVE2_BLOCK / 64));
-    const int64_t cap = (int64_t)n_cu * 4; // = the kernel's launch bound (4 x 512 threads per CU; 4 x 38 KB of LDS)
+    const int64_t cap = (int64_t)n_cu * 4; // = the kernel's launch bound (4 x 512 threads per CU; 4 x 32 KiB of LDS)
     const int64_t nb = want < cap ? want : cap;
     ApmSieve2Args args = a;
     args.n_main_blocks = (int)nb;
@@ -231,8 +163,7 @@ hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
 #endif
     void *kargs[] = {&args};
     if (a.stride == 8)
-        return hipLaunchKernel((const void *)apm_sieve8_kernel, dim3((unsigned)(nb + a.n_tail)), dim3(APM_SIEVE2_BLOCK), kargs,
-                               8192 + (size_t)(APM_SIEVE2_BLOCK / 64) * APM_SIEVE2_QUEUE * 4, s);
+        return hipLaunchKernel((const void *)apm_sieve8_kernel, dim3((unsigned)(nb + a.n_tail)), dim3(APM_SIEVE2_BLOCK), kargs, 8192, s);
     return hipLaunchKernel((const void *)apm_sieve2_kernel, dim3((unsigned)(nb + a.n_tail)), dim3(APM_SIEVE2_BLOCK), kargs, lds, s);
 }
 
@@ -443,11 +374,10 @@ __host__ __device__ constexpr int apm_verify_scap(int band) { return ((64 + 2 * 
 // image (many keys) limits the workgroups per CU
 // SAMPLED: the list comes from the stride-8 sieve (see ApmVerifyArgs::stride)
 template <int BAND, int THREADS, bool SAMPLED>
-__global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a) {
+__global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) ? 7 : 4) void apm_verify_kernel(ApmVerifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (*a.cand_n > a.cand_cap) return; // the list overflowed: the guarded fallback launches scan instead
     constexpr int NSH = 2 * BAND + 1;
     constexpr uint32_t FLUSH_AT = (64 + NSH - 1) / NSH; // the DP pass runs once it fills a wave: (survivor, shift) items
     constexpr int SCAP = apm_verify_scap(BAND);         // capacity of a wave's survivor list: FLUSH_AT - 1 + one round of 64
@@ -461,37 +391,11 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
     const uint4 *s_masks = reinterpret_cast<const uint4 *>(s_img + a.o_masks);
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_img + a.image_len);
     uint2 *s_surv = reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + wv * SCAP; // this wave's survivors {position, kid}
-    uint32_t *s_rc = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + (THREADS / 64) * SCAP); // [SHARDS] candidates in list region s
-    uint32_t *s_pre = s_rc + APM_CAND_SHARDS;                                                                                     // [SHARDS + 1] 64-candidate batches before region s
+    uint32_t *s_q = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + (THREADS / 64) * SCAP) + wv * 128; // this wave's hit queue
 
     for (int i = tid; i < (a.image_len >> 4); i += THREADS) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
     for (int i = tid; i < a.n_pats; i += THREADS) s_cnt[i] = 0u;
-    static_assert(APM_CAND_SHARDS <= THREADS, "one thread per list region below");
-    // batches (64 candidates) per list region and their exclusive prefix sums: regions 64 w .. 64 w + 63 are scanned by
-    // wave w with DPP-free shuffles, the four wave totals are added up through LDS
-    uint32_t my_nb = 0, incl = 0;
-    if (tid < APM_CAND_SHARDS) {
-        const uint32_t rc = (uint32_t)a.shard_cnt[16 * tid]; // (<= shard_cap < 2^32: no overflow happened)
-        s_rc[tid] = rc;
-        my_nb = (rc + 63u) >> 6;
-        incl = my_nb;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) s_pre[APM_CAND_SHARDS - 3 + wv] = incl; // (wave totals parked in slots this wave range never reads back early)
-    }
-    __syncthreads();
-    uint32_t wave_base = 0;
-    if (tid < APM_CAND_SHARDS) {
-        for (int w = 0; w < wv; ++w) wave_base += s_pre[APM_CAND_SHARDS - 3 + w];
-    }
-    const uint32_t total_nb = s_pre[APM_CAND_SHARDS - 3] + s_pre[APM_CAND_SHARDS - 2] + s_pre[APM_CAND_SHARDS - 1] + s_pre[APM_CAND_SHARDS];
-    __syncthreads();
-    if (tid < APM_CAND_SHARDS) s_pre[tid] = wave_base + incl - my_nb;
-    if (tid == 0) s_pre[APM_CAND_SHARDS] = total_nb;
-    __syncthreads(); // the last workgroup barrier before the final count flush
+    __syncthreads(); // the only workgroup barrier before the final count flush
 
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
@@ -506,39 +410,71 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
     // DP pass over the wave's survivor list, or moves to the next (batch, parity), or evaluates the predicate once
     // for every lane that still has a key to try at its position. ----
     uint32_t n_surv = 0; // wave-uniform
-    // the batches of all regions, in region order, are dealt to the waves in equal contiguous runs
-    const uint32_t n_batches = s_pre[APM_CAND_SHARDS];
+    // the sieve's 4 KiB blocks are dealt to the waves in equal contiguous runs; a wave compacts the hit masks of its
+    // blocks (one dword per lane and block) into a queue of positions and takes 64 of them per batch -- dense lanes
+    // across block borders, since the text comes from global memory anyway
+    constexpr uint32_t STEP = SAMPLED ? 8u : 2u; // bytes between two lookups of the sieve
     const uint32_t n_waves = (uint32_t)a.n_blocks * (THREADS / 64), my_wave = blockIdx.x * (THREADS / 64) + (uint32_t)wv;
-    uint32_t bi = (uint32_t)(((unsigned long long)n_batches * my_wave) / n_waves);
-    const uint32_t b_end = (uint32_t)(((unsigned long long)n_batches * (my_wave + 1u)) / n_waves);
-    uint32_t sh = 0; // region of batch bi: the last one with s_pre[sh] <= bi
-    for (uint32_t step = APM_CAND_SHARDS / 2; step; step >>= 1)
-        if (s_pre[sh + step] <= bi) sh += step;
-    // the candidates of the wave's batches, in order; false once the run is exhausted
+    uint64_t bi = ((uint64_t)a.n_mask_blocks * my_wave) / n_waves;
+    const uint64_t b_end = ((uint64_t)a.n_mask_blocks * (my_wave + 1u)) / n_waves;
+    // masks of the block in hand and of the AHEAD blocks after it (sparse sampled lists are bound by this chain of loads)
+    constexpr int AHEAD = SAMPLED ? 4 : 1;
+    uint32_t hm = 0, hm_q[AHEAD];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) hm_q[i] = bi + (uint64_t)i < b_end ? a.masks[(bi + (uint64_t)i) * 64 + (uint64_t)lane] : 0u;
+    uint32_t blk = 0;    // relative position of the block in hand
+    uint32_t qcount = 0; // wave-uniform
+    // the next batch: up to 64 positions (in units of STEP bytes); false once the wave's run is exhausted
     auto next_cand = [&](uint32_t &q, bool &hv) __attribute__((always_inline)) -> bool {
+        while (qcount < 64u) {
+            if (!__builtin_amdgcn_ballot_w64(hm != 0u)) { // block done: take the prefetched masks of the next one
+                if (bi >= b_end) break;
+                blk = (uint32_t)(a.tile0 + (int64_t)bi * 4096);
+                hm = hm_q[0];
+#pragma unroll
+                for (int i = 0; i + 1 < AHEAD; ++i) hm_q[i] = hm_q[i + 1];
+                ++bi;
+                hm_q[AHEAD - 1] = bi + (uint64_t)(AHEAD - 1) < b_end ? a.masks[(bi + (uint64_t)(AHEAD - 1)) * 64 + (uint64_t)lane] : 0u;
+                continue;
+            }
+            const bool has = hm != 0u;
+            const uint32_t t = has ? (uint32_t)__builtin_ctz(hm) : 0u;
+            hm &= hm - 1u;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+            const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (has) s_q[idx] = (blk + (t >> 3) * 1024u + 16u * (uint32_t)lane + (t & 7u) * STEP) / STEP;
+            qcount += (uint32_t)__builtin_popcountll(mask);
+        }
         q = 0;
         hv = false;
-        if (bi >= b_end) return false;
-        while (s_pre[sh + 1] <= bi) ++sh; // (bi < n_batches = s_pre[SHARDS]: ends at a non-empty region)
-        const uint32_t in_region = (bi - s_pre[sh]) * 64u + (uint32_t)lane;
-        hv = in_region < s_rc[sh];
-        if (hv) q = a.cand[(size_t)sh * (size_t)a.shard_cap + in_region];
-        ++bi;
+        if (qcount == 0u) return false;
+        const uint32_t nb = qcount < 64u ? qcount : 64u;
+        hv = (uint32_t)lane < nb;
+        if (hv) q = s_q[lane];
+        if (qcount > 64u) { // keep the rest for the next batch
+            const uint32_t rest = s_q[64 + lane];
+            if ((uint32_t)lane < qcount - 64u) s_q[lane] = rest;
+        }
+        qcount -= nb;
         return true;
     };
-    // two batches ahead: the list entries of batch b+2 and the text windows of batch b+1 are in flight while batch b
-    // is worked on (vmcnt counts in order: the loads of the pre-check queue behind them and wait for no more)
+    // one batch ahead: the positions of batch b+1 are formed (a matter of registers and LDS) and its text windows are in
+    // flight while batch b is worked on (vmcnt counts in order: the loads of the pre-check queue behind them and wait
+    // for no more)
     bool done = false, active = false, have = false;
     uint32_t p = 0, str = 0, s = 0, pend = 0;
-    uint32_t cur = 0, nxt = 0; // current key id | 0x8000 when it is the last of its list; index of the next slot
+    uint32_t cur = 0; // low half: current key id | 0x8000 when it is the last of its list; high half: index of the next slot
     Win win, win_n, wk; // text at the candidate position (this / the next batch); SAMPLED: at the piece the key in hand implies
-    constexpr uint32_t PSH = SAMPLED ? 3u : 1u;    // list entry -> relative position
+    constexpr uint32_t PSH = SAMPLED ? 3u : 1u;    // queue entry -> relative position
     constexpr uint32_t KBITS = SAMPLED ? 11u : 15u; // key id bits of a key-list payload; above them the block's offset in its piece
-    uint32_t q_n, q_nn;
-    bool have_n, have_nn;
-    bool ex_n = next_cand(q_n, have_n);
-    load_win((q_n << PSH) & ~3u, win_n);
-    bool ex_nn = next_cand(q_nn, have_nn);
+    uint32_t q_n = 0;
+    bool have_n = false;
+    bool ex_n = true; // (an empty batch starts the pipeline through the loop's own rotate step)
+#if APM_VERIFY_PIPE == 2
+    uint32_t q_nn = 0;
+    bool have_nn = false, ex_nn = true;
+#endif
+    load_win(0u, win_n);
     for (;;) {
         if (n_surv >= FLUSH_AT || (done && n_surv)) {
             for (uint32_t w0 = 0; w0 < n_surv * NSH; w0 += 64) { // one (survivor, shift) per lane
@@ -565,7 +501,7 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
             const uint32_t e = s_r2s[(uint32_t)s_prefix[x & 2047u] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))];
             s = p + par;
             if (e & 0x8000u) cur = e;
-            else { cur = s_slots[e]; nxt = e + 1u; }
+            else cur = (uint32_t)s_slots[e] | ((e + 1u) << 16);
             active = true;
             if constexpr (SAMPLED) { // the block at p lies r bytes inside its piece: the unit's position is p - r
                 s = p - ((cur & 0x7fffu) >> KBITS);
@@ -578,11 +514,16 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
             p = q_n << PSH; // relative position (even / a multiple of 8)
             have = have_n;
             win = win_n;
+#if APM_VERIFY_PIPE == 2
             ex_n = ex_nn;
             q_n = q_nn;
             have_n = have_nn;
             load_win((q_n << PSH) & ~3u, win_n);
             ex_nn = next_cand(q_nn, have_nn);
+#else
+            ex_n = next_cand(q_n, have_n);
+            load_win((q_n << PSH) & ~3u, win_n);
+#endif
             // code words of the 8-byte windows at p and p + 1 (16 bits each) out of the 12 bytes from p on
             str = 0;
 #pragma unroll
@@ -615,7 +556,7 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
         if (active) {
             if (cur & 0x8000u) active = false;
             else {
-                cur = s_slots[nxt++];
+                cur = (uint32_t)s_slots[cur >> 16] | ((cur & 0xffff0000u) + 0x10000u);
                 if constexpr (SAMPLED) {
                     s = p - ((cur & 0x7fffu) >> KBITS);
                     if (s > p) s = 0xffffffffu; // (in front of the shard: the pre-check's position test rejects it)
@@ -633,8 +574,8 @@ __global__ __launch_bounds__(THREADS, 4) void apm_verify_kernel(ApmVerifyArgs a)
 }
 
 static size_t apm_verify_lds_bytes_t(const ApmVerifyArgs &a, int threads) {
-    return (size_t)a.image_len + (size_t)((a.n_pats + 3) & ~3) * 4 + (size_t)(threads / 64) * (size_t)apm_verify_scap(a.band) * 8 +
-           (size_t)(2 * APM_CAND_SHARDS + 4) * 4 + 16; // image + counts + one survivor list per wave + region tables
+    return (size_t)a.image_len + (size_t)((a.n_pats + 3) & ~3) * 4 + (size_t)(threads / 64) * ((size_t)apm_verify_scap(a.band) * 8 + 128 * 4) +
+           16; // image + counts + one survivor list and one hit queue per wave
 }
 
 static const void *apm_verify_fn(int band, int threads, int stride) {
@@ -683,7 +624,7 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
     const void *fn = apm_verify_fn(a.band, threads, a.stride);
     if (!fn) return hipErrorInvalidValue;
     ApmVerifyArgs args = a;
-    args.n_blocks = max_blocks < 1 ? 1 : max_blocks; // (list length unknown on the host: a persistent grid strides over it)
+    args.n_blocks = max_blocks < 1 ? 1 : max_blocks; // (number of hits unknown on the host: a persistent grid shares the blocks)
 #ifdef APM_MEASURE
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
 #endif
