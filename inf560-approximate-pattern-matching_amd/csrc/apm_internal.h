@@ -133,12 +133,7 @@ struct ApmFilterArgs {
     int n_main_blocks;     /* set by the launcher: persistent scan workgroups */
     int n_tail;            /* extra workgroups, one per tail pattern (0: tails launched separately) */
     ApmTailArgs tail;
-    /* cand_mode 2: this launch is the fallback of the sieve + verify pipeline (apm_sieve.hip) for its patterns:
-       the normal scan, but only if the pipeline's candidate list overflowed (*cand_n > cand_cap, read on the
-       device); cand_mode 0: unconditional scan */
-    const unsigned long long *cand_n;
-    unsigned long long cand_cap;
-    int cand_mode;
+    int n_cu;              /* compute units of the device (set by the runtime; spreads the verification over the SIMDs) */
 };
 
 #define APM_TAG_EMPTY 0x5bd1e995u

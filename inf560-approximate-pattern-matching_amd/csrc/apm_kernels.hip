@@ -577,8 +577,6 @@ void apm_filter_kernel(ApmFilterArgs a) {
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
-    // fallback of the sieve + verify pipeline (apm_sieve.hip): nothing to do unless its candidate list overflowed
-    if (a.cand_mode == 2 && *a.cand_n <= a.cand_cap) return;
     // LDS: [tile 0 | tile 1 | (tile 2) | launch image (pattern bytes, hash table, key/pattern records) | queue | counts]
     // LDS-DMA: three tile buffers; the per-position classes keep a fourth so that the tile before the current
     // one stays intact and two tiles are verified in ONE pass (see the tile loop)
@@ -821,9 +819,9 @@ void apm_filter_kernel(ApmFilterArgs a) {
     };
 
     const uint32_t hshift = 32u - (uint32_t)a.lg_nb;
-    // resident slot of this workgroup on its CU (workgroups b, b+256, b+512, ... share a CU on the 256-CU part;
+    // resident slot of this workgroup on its CU (workgroups b, b + n_cu, b + 2 n_cu, ... tend to share a CU;
     // a heuristic, only the spread of the verification over the SIMDs depends on it): slots 0,1,2,3 -> 0,2,1,3
-    const int slot_on_cu = (int)(blockIdx.x >> 8);
+    const int slot_on_cu = (int)blockIdx.x / (a.n_cu > 0 ? a.n_cu : 256);
     const int rot0 = 2 * slot_on_cu + (slot_on_cu >> 1);
 
     // filter + enqueue, barrier, cooperative verification of tile t held in s_tile
@@ -1153,9 +1151,6 @@ void apm_stream_kernel(ApmFilterArgs a) {
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
-    // fallback of the sieve + verify pipeline (apm_sieve.hip): nothing to do unless its candidate list overflowed
-    // (a uniform early exit before anything is staged)
-    if (a.cand_mode == 2 && *a.cand_n <= a.cand_cap) return;
     constexpr int NSH = 2 * BAND + 1;
     constexpr bool PAIRS = (STRIDE == 1) && (BAND >= 1);
     constexpr int GRP = 4;                        // probes between two flush checks

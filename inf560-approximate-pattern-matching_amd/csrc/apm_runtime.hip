@@ -1209,6 +1209,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
             f.key_len = L.key_len;
             f.stride = L.stride;
             f.counts = d_counts;
+            f.n_cu = ds.n_cu;
             f.n_pats = (int)L.descs.size();
             f.k = ctx->k;
             f.tile_w = L.tile;

@@ -876,6 +876,61 @@ def test_window_nominated_only_by_a_shifted_piece_at_tile_start(ctx, apm, m):
     ctx.set_kernel("auto")
 
 
+@pytest.mark.parametrize("seed", [301, 302, 303, 304, 305, 306])
+def test_sieve_pipeline_vs_full_dp_at_scale(apm, seed):
+    """Random pattern sets (lengths 12..128 mixed, k = 2..5, patterns cut from the text and edited) on 48 MiB of device
+    text over small alphabets -- millions of sieve hits, thousands of verify batches per wave, real DP work and bursts
+    of matches: the sieve + verify pipeline (AUTO/BANDED) must give the counts of the forced full-DP BITPAR kernel.
+    One seed in three runs the sampled form (all pieces >= 15 bytes)."""
+    import torch
+    rnd = random.Random(seed)
+    n = 48 << 20
+    alpha = rnd.choice([b"ACGT", b"ACGT", b"ACG", b"ACGTN"])
+    k = rnd.choice([2, 3, 3, 4, 5])
+    sampled = seed % 3 == 0
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    idx = torch.randint(0, len(alpha), (n,), generator=g, dtype=torch.uint8)
+    lut = torch.tensor(list(alpha), dtype=torch.uint8)
+    host = lut[idx.long()]
+    if seed % 2 == 0:  # tandem repeats: stretches where every window is a candidate and matches come in bursts
+        unit = host[:37].clone()
+        for off in range(1 << 20, n - (1 << 16), 5 << 20):
+            host[off:off + 37 * 800] = unit.repeat(800)
+    text_bytes = host.numpy().tobytes()
+    pats = []
+    for i in range(rnd.randint(8, 40)):
+        m = rnd.randint(15 * (k + 1), 128) if sampled else rnd.randint(4 * (k + 1), 128)
+        o = rnd.randrange(0, n - m)
+        p = bytearray(text_bytes[o:o + m])
+        for _e in range(rnd.randint(0, k)):
+            r, pos = rnd.random(), rnd.randrange(len(p))
+            if r < 0.5:
+                p[pos] = rnd.choice(alpha)
+            elif r < 0.75 and len(p) > 1:
+                del p[pos]
+                p.append(rnd.choice(alpha))
+            else:
+                p.insert(pos, rnd.choice(alpha))
+                p.pop()
+        pats.append(bytes(p))
+    text = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+    text[:n] = host.to("cuda:0")
+    cnt = torch.zeros(len(pats), dtype=torch.int64, device="cuda:0")
+    with apm.ApmContext(device=0) as c2:
+        c2.set_patterns(pats, k)
+        assert c2.stat("sieve_on") == 1 and c2.stat("sieve_stride") == (8 if sampled else 1)
+        got = {}
+        for variant in ("auto", "bitpar"):
+            c2.set_kernel(variant)
+            cnt.zero_()
+            torch.cuda.synchronize()
+            c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())
+            c2.synchronize()
+            got[variant] = cnt.cpu().tolist()
+        assert got["auto"] == got["bitpar"], (seed, k, sampled, [len(p) for p in pats])
+        assert sum(got["auto"]) >= len(pats) // 2
+
+
 def _soak_seeds(default):
     """APM_SOAK_SEEDS=a-b widens the soak tests for a bug hunt (the suite itself runs the default seeds)."""
     spec = os.environ.get("APM_SOAK_SEEDS")
