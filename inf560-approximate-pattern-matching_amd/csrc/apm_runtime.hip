@@ -101,6 +101,7 @@ struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns 
     int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0, o_masks = 0;
     int m_max = 0, m_min = 0;
     int blocks_per_cu = 0, threads = 256; // launch geometry (occupancy query, cached)
+    int fused_blocks_per_cu = 0, fused_threads = 0; // the same for the fused form (threads < 0: it does not fit a CU)
 };
 
 struct SievePlan {         // ONE text pass (apm_sieve2_kernel) for every per-position key of the pattern set
@@ -1029,14 +1030,16 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         const int64_t p_lo = std::max<int64_t>(0, jb - band) & ~(int64_t)15;
         const int64_t p_hi = std::min<int64_t>(avail, je + ctx->sieve.m_max + band);
         if (p_hi > p_lo && avail_pad >= 16 && avail_pad < ((int64_t)1 << 32) - 4096) {
-            // FUSED form (per-position sets whose image leaves LDS room for sixteen wave buffers): one kernel per verify
-            // group, the text is read once, no candidate list and therefore no overflow case and no fallback launches.
-            // Measured SLOWER than the two-kernel pipeline on MI355X (cfg3 0.68 vs 0.50 ms, cfg5 0.82 vs 0.69 ms per GiB:
-            // 4 waves per SIMD instead of 8 and half-empty verification lanes cost more than the second read saves), so
-            // it is opt-in: APM_FUSED=1 (A/B aid; the tests run both forms).
-            static const int fused_env = getenv("APM_FUSED") ? atoi(getenv("APM_FUSED")) : 0;
-            bool fused_ok = fused_env && ctx->sieve.stride == 1;
+            // FUSED form: one kernel per verify group sieves and verifies; the text leaves HBM once, no masks.  Measured on
+            // MI355X (profiles/r02/fused_ab.txt): the sampled pipeline gains 15 % (cfg4 0.268 -> 0.228 ms per GiB: its
+            // sieve is a few instructions per KiB, the verification hides behind the stream), the per-position one is
+            // latency bound in either form and loses occupancy to the bigger kernel (cfg3 0.50 -> 0.48 at best, cfg5
+            // 0.64 -> 1.08).  So: fused when the sieve is sampled; APM_FUSED=1 / 0 forces it on / off (A/B aid, and the
+            // tests run both forms).
+            static const int fused_env = getenv("APM_FUSED") ? atoi(getenv("APM_FUSED")) : -1;
+            bool fused_ok = fused_env < 0 ? ctx->sieve.stride == 8 : fused_env != 0;
             std::vector<ApmFusedArgs> fargs;
+            std::vector<size_t> fa_index; // fargs[i] belongs to launches[fa_index[i]]
             for (size_t v = 0; fused_ok && v < ctx->sieve.launches.size(); ++v) {
                 VerifyLaunch &V = ctx->sieve.launches[v];
                 ApmFusedArgs fa{};
@@ -1046,7 +1049,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 fa.s.nchunks = (p_hi - p_lo + 1023) / 1024;
                 fa.s.bitmap = reinterpret_cast<const uint4 *>(ds.d_sieve_bmp);
                 fa.s.code_shift = ctx->sieve.code_shift;
-                fa.s.stride = 1;
+                fa.s.stride = ctx->sieve.stride;
                 ApmVerifyArgs &va = fa.v;
                 va.text = d_text;
                 va.avail = avail;
@@ -1072,9 +1075,17 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 va.k = ctx->k;
                 va.band = band;
                 va.code_shift = ctx->sieve.code_shift;
-                va.stride = 1;
-                if (apm_fused_lds_bytes(fa) > (size_t)160 * 1024) fused_ok = false;
-                if (va.je > jb) fargs.push_back(fa);
+                va.stride = ctx->sieve.stride;
+#ifdef APM_MEASURE
+                if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, 64));
+                va.stats = ds.d_stats;
+#endif
+                if (!V.fused_threads) {
+                    V.fused_blocks_per_cu = apm_fused_geometry(fa, &V.fused_threads);
+                    if (V.fused_blocks_per_cu < 1) V.fused_threads = -1; // does not fit a CU
+                }
+                if (V.fused_threads < 64) fused_ok = false;
+                if (va.je > jb) { fargs.push_back(fa); fa_index.push_back(v); }
             }
             if (fused_ok) {
                 for (ApmFusedArgs &fa : fargs) {
@@ -1083,7 +1094,11 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                         fa.s.tail = ta;
                         tails_pending = false;
                     }
-                    HIP_TRY(ctx, apm_launch_fused(fa, ds.n_cu, ds.stream));
+                    const VerifyLaunch &V = ctx->sieve.launches[fa_index[&fa - fargs.data()]];
+#ifdef APM_MEASURE
+                    HIP_TRY(ctx, hipMemsetAsync(ds.d_stats, 0, 64, ds.stream));
+#endif
+                    HIP_TRY(ctx, apm_launch_fused(fa, V.fused_threads, ds.n_cu * V.fused_blocks_per_cu, ds.stream));
                     { const int nrc = note_launch(ctx, ds, "fused"); if (nrc) return nrc; }
                 }
                 fused_run = true;
@@ -1919,8 +1934,14 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     if (n == "sieve_mask_bytes") { *value = (double)ds.last_mask_blocks * 256.0; return APM_OK; }
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }
     if (n == "verify_image_bytes") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].image.size(); return APM_OK; }
-    if (n == "verify_blocks_per_cu") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].blocks_per_cu; return APM_OK; }
-    if (n == "verify_threads") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].threads; return APM_OK; }
+    if (n == "verify_blocks_per_cu") { // (of the form the last call ran)
+        *value = ctx->sieve.launches.empty() ? 0.0 : (double)(ds.last_fused ? ctx->sieve.launches[0].fused_blocks_per_cu : ctx->sieve.launches[0].blocks_per_cu);
+        return APM_OK;
+    }
+    if (n == "verify_threads") {
+        *value = ctx->sieve.launches.empty() ? 0.0 : (double)(ds.last_fused ? ctx->sieve.launches[0].fused_threads : ctx->sieve.launches[0].threads);
+        return APM_OK;
+    }
     if (n == "sieve_candidates") { // hits of the last call's sieve: popcount over its masks (synchronises with the stream)
         *value = 0;
         if (!ds.d_masks || ds.last_mask_blocks <= 0) return APM_OK;

@@ -73,18 +73,19 @@ struct ApmVerifyArgs {
 #endif
 };
 
-/* FUSED form of the pipeline for per-position key sets whose LDS image leaves room for it (opt-in, APM_FUSED=1:
- * measured slower than the two kernels, see apm_runtime.hip): ONE kernel, the text is read from HBM once.  A wave stages the 4 KiB it has just sieved (+ 64-byte halos) in its own LDS buffer and verifies
- * the block's hits out of it on the spot; no candidate list, no second read, no overflow case.  `v` carries the verify
- * image and records (its list fields are unused). */
+/* FUSED form of the pipeline: ONE kernel, the text leaves HBM once.  Every wave sieves its own 4 KiB blocks and
+ * feeds the hits straight into the verify batches (the same code as the verify launch: apm_verify_body); the windows
+ * are gathered from global memory, where the lines the wave has just streamed are still in the caches.  No masks, no
+ * second launch.  `s` carries the sieve side (text, tile0, nchunks, bitmap, tail workgroups), `v` the verify image and
+ * records (its masks fields are unused). */
 struct ApmFusedArgs {
-    ApmSieve2Args s; /* text, avail_pad, tile0, nchunks, bitmap, code_shift, n_main_blocks, n_tail, tail (list fields unused) */
+    ApmSieve2Args s;
     ApmVerifyArgs v;
 };
-#define APM_FUSED_BLOCK 1024
-#define APM_FUSED_TEXT (64 + 4096 + 64) /* per-wave text buffer: front halo | block | back halo */
-hipError_t apm_launch_fused(const ApmFusedArgs &a, int n_cu, hipStream_t s);
-size_t apm_fused_lds_bytes(const ApmFusedArgs &a);
+#define APM_FUSED_MAX_THREADS 896 /* 14 waves: two workgroups put 7 waves on every SIMD */
+hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, hipStream_t s);
+size_t apm_fused_lds_bytes(const ApmFusedArgs &a, int threads);
+int apm_fused_geometry(const ApmFusedArgs &a, int *threads); /* workgroups per CU; *threads = workgroup size (0: does not fit) */
 
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s);
 hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, hipStream_t s);

@@ -21,6 +21,9 @@
 #include "apm_device.h"
 #include "apm_sieve.h"
 
+#ifndef APM_FUSED_PIPE
+#define APM_FUSED_PIPE 1 /* the same for the fused form */
+#endif
 #ifndef APM_VERIFY_PIPE
 #define APM_VERIFY_PIPE 2 /* batches formed ahead of the one in hand (measured: 2 beats 1 by 17 % on cfg3: the window loads of batch b+1 then do not wait for the queue reads that form it) */
 #endif
@@ -373,15 +376,20 @@ __host__ __device__ constexpr int apm_verify_scap(int band) { return ((64 + 2 * 
 // THREADS = 256 or 512: the bigger workgroup shares one LDS image among eight waves -- more waves per CU when the
 // image (many keys) limits the workgroups per CU
 // SAMPLED: the list comes from the stride-8 sieve (see ApmVerifyArgs::stride)
-template <int BAND, int THREADS, bool SAMPLED>
-__global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) ? 7 : 4) void apm_verify_kernel(ApmVerifyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// FUSED: the hit masks do not come from a sieve launch -- the wave sieves its blocks itself (sv: the sieve's arguments;
+// stride 1: its 32 KiB bitmap leads the LDS, the image follows; stride 8: the image's own bitmap is the sieve's) and
+// verifies the hits in the same batches of 64 across block borders, the windows gathered from global memory (L2 /
+// Infinity Cache: the wave streamed those lines a moment ago).  One launch, the text leaves HBM once, no masks.
+// THREADS_T = 0: the workgroup size is the launch's (a multiple of 64).
+template <int BAND, int THREADS_T, bool SAMPLED, bool FUSED>
+__device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const ApmSieve2Args *sv, uint8_t *smem) {
+    const int THREADS = THREADS_T ? THREADS_T : (int)blockDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NSH = 2 * BAND + 1;
     constexpr uint32_t FLUSH_AT = (64 + NSH - 1) / NSH; // the DP pass runs once it fills a wave: (survivor, shift) items
     constexpr int SCAP = apm_verify_scap(BAND);         // capacity of a wave's survivor list: FLUSH_AT - 1 + one round of 64
-    uint8_t *s_img = smem;
+    uint8_t *s_img = smem + ((FUSED && !SAMPLED) ? 32768 : 0);
     const uint32_t *s_bmp = reinterpret_cast<const uint32_t *>(s_img);
     const uint16_t *s_prefix = reinterpret_cast<const uint16_t *>(s_img + a.o_prefix);
     const uint16_t *s_r2s = reinterpret_cast<const uint16_t *>(s_img + a.o_r2s);
@@ -393,6 +401,8 @@ __global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) 
     uint2 *s_surv = reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + wv * SCAP; // this wave's survivors {position, kid}
     uint32_t *s_q = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + (THREADS / 64) * SCAP) + wv * 128; // this wave's hit queue
 
+    if constexpr (FUSED && !SAMPLED)
+        for (int i = tid; i < 2048; i += THREADS) reinterpret_cast<uint4 *>(smem)[i] = sv->bitmap[i];
     for (int i = tid; i < (a.image_len >> 4); i += THREADS) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
     for (int i = tid; i < a.n_pats; i += THREADS) s_cnt[i] = 0u;
     __syncthreads(); // the only workgroup barrier before the final count flush
@@ -414,20 +424,85 @@ __global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) 
     // blocks (one dword per lane and block) into a queue of positions and takes 64 of them per batch -- dense lanes
     // across block borders, since the text comes from global memory anyway
     constexpr uint32_t STEP = SAMPLED ? 8u : 2u; // bytes between two lookups of the sieve
-    const uint32_t n_waves = (uint32_t)a.n_blocks * (THREADS / 64), my_wave = blockIdx.x * (THREADS / 64) + (uint32_t)wv;
-    uint64_t bi = ((uint64_t)a.n_mask_blocks * my_wave) / n_waves;
-    const uint64_t b_end = ((uint64_t)a.n_mask_blocks * (my_wave + 1u)) / n_waves;
+    const uint32_t n_waves = (uint32_t)a.n_blocks * (uint32_t)(THREADS / 64), my_wave = blockIdx.x * (uint32_t)(THREADS / 64) + (uint32_t)wv;
+    uint64_t bi = FUSED ? 0 : ((uint64_t)a.n_mask_blocks * my_wave) / n_waves;
+    const uint64_t b_end = FUSED ? 0 : ((uint64_t)a.n_mask_blocks * (my_wave + 1u)) / n_waves;
     // masks of the block in hand and of the AHEAD blocks after it (sparse sampled lists are bound by this chain of loads)
-    constexpr int AHEAD = SAMPLED ? 4 : 1;
+    constexpr int AHEAD = FUSED ? 1 : (SAMPLED ? 4 : 1);
     uint32_t hm = 0, hm_q[AHEAD];
+    if constexpr (!FUSED) {
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i) hm_q[i] = bi + (uint64_t)i < b_end ? a.masks[(bi + (uint64_t)i) * 64 + (uint64_t)lane] : 0u;
+        for (int i = 0; i < AHEAD; ++i) hm_q[i] = bi + (uint64_t)i < b_end ? a.masks[(bi + (uint64_t)i) * 64 + (uint64_t)lane] : 0u;
+    }
     uint32_t blk = 0;    // relative position of the block in hand
     uint32_t qcount = 0; // wave-uniform
+    // FUSED: the wave's blocks are my_wave, my_wave + n_waves, ... (neighbouring waves stream neighbouring blocks)
+    uint32_t fb = my_wave;
+    const uint32_t n_fb = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : 0u, nch32 = FUSED ? (uint32_t)sv->nchunks : 0u;
+    const uint32_t tile0 = FUSED ? (uint32_t)sv->tile0 : 0u;
+    uint32_t pf = 0; // one byte per 64 of the wave's NEXT block, loaded only to have its lines on their way (kept alive below)
+    auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
+    // hit mask of this lane for the block at relative position b0 (see ApmSieve2Args::masks for the bit layout)
+    auto sieve_block = [&](uint32_t b0) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t g = b0 + 16u * (uint32_t)lane, c0 = fb * 4u;
+        const uint32_t nxt = fb + n_waves < n_fb ? b0 + n_waves * 4096u + 64u * (uint32_t)lane : 0xfffffff0u;
+        uint32_t out = 0;
+        if constexpr (SAMPLED) { // one lookup per 8 bytes in the image's bitmap over 16-bit code words (apm_sieve8_kernel)
+            u32x4 r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g + 1024u * j), 0, 0);
+            asm volatile("" ::"v"(pf));
+            pf = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)nxt, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t slo = pack4(r[j].x) | (pack4(r[j].y) << 8) | (pack4(r[j].z) << 16) | (pack4(r[j].w) << 24);
+                const uint32_t w0 = s_bmp[slo & 2047u], w1 = s_bmp[(slo >> 16) & 2047u];
+                const uint32_t h = ((w0 >> ((slo >> 11) & 31u)) & 1u) | (((w1 >> (slo >> 27)) & 1u) << 1);
+                out |= (c0 + j < nch32 ? h : 0u) << (8 * j);
+            }
+        } else { // one lookup per even position in the 32 KiB bitmap over 18-bit code words at LDS address 0 (apm_sieve2_kernel)
+            // (chunks behind the scanned range are loaded all the same -- text or zeros -- since the windows of the last
+            // valid chunk run into them; only their own hits are dropped)
+            u32x4 r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g + 1024u * j), 0, 0);
+            const v2u32 tl = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(b0 + 4096u), 0, 0); // the 8 bytes behind the block
+            asm volatile("" ::"v"(pf));
+            pf = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)nxt, 0, 0);
+            uint32_t slo[5]; // codes of the lane's 16 bytes, chunk by chunk; [4]: of the 8 bytes behind the block
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slo[j] = pack4(r[j].x) | (pack4(r[j].y) << 8) | (pack4(r[j].z) << 16) | (pack4(r[j].w) << 24);
+            slo[4] = pack4(tl.x) | (pack4(tl.y) << 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // codes of the 8 bytes behind the lane's 16 = the low half of the next lane's string (lane 63: of the
+                // next chunk's lane 0): one DPP move (wave_shl:1; the last lane keeps `old`)
+                const uint32_t nx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slo[j + 1]);
+                const uint32_t shi = (uint32_t)__builtin_amdgcn_update_dpp((int)nx0, (int)slo[j], 0x130, 0xf, 0xf, false);
+                uint32_t hits = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const uint32_t y = t ? __builtin_amdgcn_alignbit(shi, slo[j], 4u * (uint32_t)t - 2u) : (slo[j] << 2);
+                    const uint32_t word = *(const apm_lds_u32 *)(uintptr_t)(y & 0x7ffcu);
+                    hits = __builtin_amdgcn_alignbit(word >> ((y >> 15) & 31u), hits, 1u);
+                }
+                out |= (c0 + j < nch32 ? hits >> 24 : 0u) << (8 * j);
+                __builtin_amdgcn_sched_barrier(0); // chunk by chunk: the window state of the batches in flight is live here
+            }
+        }
+        return out;
+    };
     // the next batch: up to 64 positions (in units of STEP bytes); false once the wave's run is exhausted
     auto next_cand = [&](uint32_t &q, bool &hv) __attribute__((always_inline)) -> bool {
         while (qcount < 64u) {
             if (!__builtin_amdgcn_ballot_w64(hm != 0u)) { // block done: take the prefetched masks of the next one
+                if constexpr (FUSED) { // ... or sieve the wave's next block
+                    if (fb >= n_fb) break;
+                    blk = tile0 + fb * 4096u;
+                    hm = sieve_block(blk);
+                    fb += n_waves;
+                    continue;
+                }
                 if (bi >= b_end) break;
                 blk = (uint32_t)(a.tile0 + (int64_t)bi * 4096);
                 hm = hm_q[0];
@@ -470,10 +545,9 @@ __global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) 
     uint32_t q_n = 0;
     bool have_n = false;
     bool ex_n = true; // (an empty batch starts the pipeline through the loop's own rotate step)
-#if APM_VERIFY_PIPE == 2
-    uint32_t q_nn = 0;
+    constexpr int PIPE = FUSED ? APM_FUSED_PIPE : APM_VERIFY_PIPE;
+    uint32_t q_nn = 0; // (PIPE == 2)
     bool have_nn = false, ex_nn = true;
-#endif
     load_win(0u, win_n);
     for (;;) {
         if (n_surv >= FLUSH_AT || (done && n_surv)) {
@@ -514,16 +588,16 @@ __global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) 
             p = q_n << PSH; // relative position (even / a multiple of 8)
             have = have_n;
             win = win_n;
-#if APM_VERIFY_PIPE == 2
-            ex_n = ex_nn;
-            q_n = q_nn;
-            have_n = have_nn;
-            load_win((q_n << PSH) & ~3u, win_n);
-            ex_nn = next_cand(q_nn, have_nn);
-#else
-            ex_n = next_cand(q_n, have_n);
-            load_win((q_n << PSH) & ~3u, win_n);
-#endif
+            if constexpr (PIPE == 2) {
+                ex_n = ex_nn;
+                q_n = q_nn;
+                have_n = have_nn;
+                load_win((q_n << PSH) & ~3u, win_n);
+                ex_nn = next_cand(q_nn, have_nn);
+            } else {
+                ex_n = next_cand(q_n, have_n);
+                load_win((q_n << PSH) & ~3u, win_n);
+            }
             // code words of the 8-byte windows at p and p + 1 (16 bits each) out of the 12 bytes from p on
             str = 0;
 #pragma unroll
@@ -566,11 +640,18 @@ __global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) 
         }
     }
 
+    asm volatile("" ::"v"(pf));
     __syncthreads();
     for (int i = tid; i < a.n_pats; i += THREADS) {
         const uint32_t cnt = s_cnt[i];
         if (cnt) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)cnt);
     }
+}
+
+template <int BAND, int THREADS, bool SAMPLED>
+__global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) ? 7 : 4) void apm_verify_kernel(ApmVerifyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    apm_verify_body<BAND, THREADS, SAMPLED, false>(a, nullptr, smem);
 }
 
 static size_t apm_verify_lds_bytes_t(const ApmVerifyArgs &a, int threads) {
@@ -633,225 +714,72 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
 }
 
 // ---------------------------------------------------------------------------
-// FUSED: sieve + verify in one pass (see ApmFusedArgs).  1024-thread workgroups, one per CU: sixteen wave-autonomous
-// scanners share the sieve bitmap and the verify image; each owns a 4 KiB (+ halos) text buffer, a 128-entry hit queue
-// and a survivor list.  LDS: 32 KiB + image + 16 x ~5 KiB.
+// FUSED: sieve + verify in one launch (apm_verify_body<.., FUSED = true>; see ApmFusedArgs)
 // ---------------------------------------------------------------------------
-template <int BAND>
-__global__ __launch_bounds__(APM_FUSED_BLOCK, 4) void apm_fused_kernel(ApmFusedArgs f) {
+template <int BAND, bool SAMPLED>
+__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND <= 1 ? 7 : 6) : 5) void apm_fused_kernel(ApmFusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const ApmSieve2Args &a = f.s;
-    const ApmVerifyArgs &va = f.v;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if ((int)blockIdx.x >= a.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
-        apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
+    if ((int)blockIdx.x >= f.s.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
+        apm_tail_body(f.s.tail, (int)blockIdx.x - f.s.n_main_blocks, reinterpret_cast<uint4 *>(smem), (int)threadIdx.x);
         return;
     }
-    constexpr int NSH = 2 * BAND + 1;
-    constexpr uint32_t FLUSH_AT = (64 + NSH - 1) / NSH;
-    constexpr int SCAP = apm_verify_scap(BAND);
-    constexpr int WAVES = APM_FUSED_BLOCK / 64;
-    uint8_t *s_img = smem + 32768;
-    const uint32_t *s_bmp = reinterpret_cast<const uint32_t *>(s_img);
-    const uint16_t *s_prefix = reinterpret_cast<const uint16_t *>(s_img + va.o_prefix);
-    const uint16_t *s_r2s = reinterpret_cast<const uint16_t *>(s_img + va.o_r2s);
-    const uint16_t *s_slots = reinterpret_cast<const uint16_t *>(s_img + va.o_slots);
-    const uint32_t *s_kext = reinterpret_cast<const uint32_t *>(s_img + va.o_kext);
-    const uint8_t *s_pat = s_img + va.o_pat;
-    const uint4 *s_masks = reinterpret_cast<const uint4 *>(s_img + va.o_masks);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_img + va.image_len);
-    uint8_t *s_wave = reinterpret_cast<uint8_t *>(s_cnt + ((va.n_pats + 3) & ~3)) + (size_t)wv * (APM_FUSED_TEXT + 128 * 2 + SCAP * 8);
-    uint8_t *s_text = s_wave;                                                       // this wave's block: [front halo 64 | 4096 | back halo 64]
-    uint16_t *s_q = reinterpret_cast<uint16_t *>(s_wave + APM_FUSED_TEXT);         // hit queue: (position - block start) / 2
-    uint2 *s_surv = reinterpret_cast<uint2 *>(s_wave + APM_FUSED_TEXT + 128 * 2);  // survivors {position, kid}
+    apm_verify_body<BAND, 0, SAMPLED, true>(f.v, &f.s, smem);
+}
 
-    for (int i = tid; i < 2048; i += APM_FUSED_BLOCK) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
-    for (int i = tid; i < (va.image_len >> 4); i += APM_FUSED_BLOCK) reinterpret_cast<uint4 *>(s_img)[i] = va.image[i];
-    for (int i = tid; i < va.n_pats; i += APM_FUSED_BLOCK) s_cnt[i] = 0u;
-    __syncthreads(); // the only workgroup barrier before the final count flush
-
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
-    ApmVerifyCore<BAND> core{va, rs, (uint32_t)va.avail, s_kext, s_masks, s_pat, s_cnt, lane};
-    const int64_t W = (int64_t)a.n_main_blocks * WAVES;
-    const int64_t nch = a.nchunks;
-    const uint32_t cs = (uint32_t)a.code_shift;
-
-    // one load per lane per chunk (+ the 8 bytes behind the lane's 16) through the shard-wide resource: zeros past the end
-    auto load_chunk = [&](int64_t cc, u32x4 &r, v2u32 &e) __attribute__((always_inline)) {
-        const uint32_t g = cc < nch ? (uint32_t)(a.tile0 + cc * 1024) + 16u * (uint32_t)lane : 0xfffffff0u;
-        r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)g, 0, 0);
-        e = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(g + 16u), 0, 0);
-    };
-    // halos of the 4 KiB block at relative position blk: lanes 0..3 the 64 bytes in front, lanes 4..7 the 64 behind
-    auto load_halo = [&](int64_t cc, u32x4 &h) __attribute__((always_inline)) {
-        const uint32_t blk = (uint32_t)(a.tile0 + cc * 1024);
-        const uint32_t g = (cc < nch && lane < 8) ? (lane < 4 ? blk - 64u + 16u * (uint32_t)lane : blk + 4096u + 16u * (uint32_t)(lane - 4)) : 0xfffffff0u;
-        h = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)g, 0, 0); // (blk < 64: wraps to a huge offset -> zeros, as every byte outside the shard)
-    };
-    auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
-    auto hit_bits = [&](const u32x4 &v, const v2u32 &e) __attribute__((always_inline)) { // bits 0..7 = even positions 0, 2, .. 14 of the lane
-        const uint32_t slo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24);
-        const uint32_t shi = pack4(e.x) | (pack4(e.y) << 8);
-        uint32_t hits = 0;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const uint32_t y = t ? __builtin_amdgcn_alignbit(shi, slo, 4u * (uint32_t)t - 2u) : (slo << 2);
-            const uint32_t word = *(const apm_lds_u32 *)(uintptr_t)(y & 0x7ffcu);
-            hits = __builtin_amdgcn_alignbit(word >> ((y >> 15) & 31u), hits, 1u);
-        }
-        return hits >> 24;
-    };
-    // six text dwords from the 4-byte aligned relative position a0: out of the wave's LDS block when it holds them
-    uint32_t blk = 0; // relative position of the staged block (wave-uniform)
-    auto load_win = [&](uint32_t a0, ApmWin &o) __attribute__((always_inline)) {
-        const uint32_t d = a0 - (blk - 64u); // offset inside the buffer
-        if (d <= (uint32_t)(APM_FUSED_TEXT - 24)) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(s_text + d);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) o.w[i] = q[i];
-        } else {
-            core.load_global(a0, o);
-        }
-    };
-
-    uint32_t n_surv = 0; // wave-uniform
-    auto dp_pass = [&]() __attribute__((always_inline)) {
-        for (uint32_t w0 = 0; w0 < n_surv * NSH; w0 += 64) { // one (survivor, shift) per lane
-            const uint32_t wi = w0 + (uint32_t)lane;
-            const bool live = wi < n_surv * NSH;
-            const uint2 e = live ? s_surv[wi / NSH] : make_uint2(0u, 0u);
-            const int dl = (int)(wi % NSH) - BAND;
-            uint32_t wpat = 0, wj = 0, word = 0;
-            const bool hit = live && core.dp_match(e.y, e.x, dl, wpat, wj, word);
-            core.count_matches(hit, wpat, wj, word);
-        }
-        n_surv = 0;
-    };
-
-    int64_t c = ((int64_t)blockIdx.x * WAVES + wv) * 4; // four neighbouring chunks (one 4 KiB block) per wave and round
-    u32x4 r0, r1, r2, r3, hl;
-    v2u32 e0, e1, e2, e3;
-    load_chunk(c, r0, e0);
-    load_chunk(c + 1, r1, e1);
-    load_chunk(c + 2, r2, e2);
-    load_chunk(c + 3, r3, e3);
-    load_halo(c, hl);
-    for (; c < nch; c += 4 * W) {
-        blk = (uint32_t)(a.tile0 + c * 1024);
-        // stage the block, look its even positions up; the loads of the next block are on their way meanwhile
-        uint32_t hm; // this lane's hits: bit 8 j + t = even position 2 t of the lane's 16 bytes in chunk j
-        {
-            const u32x4 v0 = r0, v1 = r1, v2 = r2, v3 = r3, vh = hl;
-            const v2u32 x0 = e0, x1 = e1, x2 = e2, x3 = e3;
-            load_chunk(c + 4 * W, r0, e0);
-            load_chunk(c + 4 * W + 1, r1, e1);
-            load_chunk(c + 4 * W + 2, r2, e2);
-            load_chunk(c + 4 * W + 3, r3, e3);
-            load_halo(c + 4 * W, hl);
-            u32x4 *tb = reinterpret_cast<u32x4 *>(s_text + 64 + 16 * lane);
-            tb[0] = v0;
-            tb[64] = v1;
-            tb[128] = v2;
-            tb[192] = v3;
-            if (lane < 8) *reinterpret_cast<u32x4 *>(s_text + (lane < 4 ? 16 * lane : 64 + 4096 + 16 * (lane - 4))) = vh;
-            hm = hit_bits(v0, x0) | (hit_bits(v1, x1) << 8) | (hit_bits(v2, x2) << 16) | (hit_bits(v3, x3) << 24);
-            // (chunks past the end read as zeros; a zero block may hit the bitmap, the position test of the pre-check rejects it)
-        }
-        uint32_t qcount = 0; // wave-uniform
-        for (;;) {
-            // refill the queue from the hit masks, one hit per lane and round
-            while (qcount < 64u && __builtin_amdgcn_ballot_w64(hm != 0u)) {
-                const bool has = hm != 0u;
-                const uint32_t t = has ? (uint32_t)__builtin_ctz(hm) : 0u;
-                hm &= hm - 1u;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
-                const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (has) s_q[idx] = (uint16_t)((t >> 3) * 512u + 8u * (uint32_t)lane + (t & 7u));
-                qcount += (uint32_t)__builtin_popcountll(mask);
-            }
-            if (qcount == 0u) break;
-            const uint32_t nb = qcount < 64u ? qcount : 64u;
-            const bool have = (uint32_t)lane < nb;
-            const uint32_t p = have ? blk + 2u * (uint32_t)s_q[lane] : 0u; // even relative position
-            if (qcount > 64u) { // keep the rest for the next batch
-                const uint16_t rest = s_q[64 + lane];
-                if ((uint32_t)lane < qcount - 64u) s_q[lane] = rest;
-            }
-            qcount -= nb;
-            // ---- one batch of <= 64 candidates, text out of the wave's LDS block ----
-            ApmWin win;
-            load_win(p & ~3u, win);
-            uint32_t str = 0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const uint32_t b4 = __builtin_amdgcn_alignbyte(win.w[i + 1], win.w[i], p & 3u);
-                str |= apm_udot4((b4 >> cs) & 0x03030303u, 0x40100401u) << (8 * i);
-            }
-            const uint32_t x0 = str & 0xffffu, x1 = (str >> 2) & 0xffffu;
-            uint32_t pend = have ? (((s_bmp[x0 & 2047u] >> (x0 >> 11)) & 1u) | (((s_bmp[x1 & 2047u] >> (x1 >> 11)) & 1u) << 1)) : 0u;
-            bool active = false;
-            uint32_t s = 0, cur = 0, nxt = 0;
-            for (;;) {
-                if (!active && pend) { // next of the lane's (at most two) hit positions: key list by rank
-                    const uint32_t par = (pend & 1u) ? 0u : 1u;
-                    pend &= pend - 1u;
-                    const uint32_t x = (str >> (2u * par)) & 0xffffu, bit = x >> 11;
-                    const uint32_t word = s_bmp[x & 2047u];
-                    const uint32_t e = s_r2s[(uint32_t)s_prefix[x & 2047u] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))];
-                    s = p + par;
-                    if (e & 0x8000u) cur = e;
-                    else { cur = s_slots[e]; nxt = e + 1u; }
-                    active = true;
-                }
-                if (!__builtin_amdgcn_ballot_w64(active)) break;
-                bool ok = false;
-                if (active) ok = core.stage1(cur & 0x7fffu, s, win, load_win);
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
-                if (mask) { // survivors -> the wave's list; at most FLUSH_AT - 1 + 64 entries
-                    const uint32_t idx = n_surv + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (ok) s_surv[idx] = make_uint2(s, cur & 0x7fffu);
-                    n_surv += (uint32_t)__builtin_popcountll(mask);
-                }
-                if (active) {
-                    if (cur & 0x8000u) active = false;
-                    else cur = s_slots[nxt++];
-                }
-                if (n_surv >= FLUSH_AT) dp_pass();
-            }
-        }
-    }
-    if (n_surv) dp_pass();
-
-    __syncthreads();
-    for (int i = tid; i < va.n_pats; i += APM_FUSED_BLOCK) {
-        const uint32_t cnt = s_cnt[i];
-        if (cnt) atomicAdd(&va.counts[va.pats[i].index], (unsigned long long)cnt);
+static const void *apm_fused_fn(int band, int stride) {
+    switch (band) {
+    case 0: return stride == 8 ? (const void *)apm_fused_kernel<0, true> : (const void *)apm_fused_kernel<0, false>;
+    case 1: return stride == 8 ? (const void *)apm_fused_kernel<1, true> : (const void *)apm_fused_kernel<1, false>;
+    case 2: return stride == 8 ? (const void *)apm_fused_kernel<2, true> : (const void *)apm_fused_kernel<2, false>;
+    case 3: return stride == 8 ? (const void *)apm_fused_kernel<3, true> : (const void *)apm_fused_kernel<3, false>;
+    default: return nullptr;
     }
 }
 
-size_t apm_fused_lds_bytes(const ApmFusedArgs &a) {
-    return 32768 + (size_t)a.v.image_len + (size_t)((a.v.n_pats + 3) & ~3) * 4 +
-           (size_t)(APM_FUSED_BLOCK / 64) * (size_t)(APM_FUSED_TEXT + 128 * 2 + apm_verify_scap(a.v.band) * 8) + 16;
+size_t apm_fused_lds_bytes(const ApmFusedArgs &a, int threads) {
+    const size_t need = (a.s.stride == 8 ? 0 : 32768) + apm_verify_lds_bytes_t(a.v, threads);
+    return need < 4096 + 256 ? 4096 + 256 : need; // (the tail workgroups' tables)
 }
 
-hipError_t apm_launch_fused(const ApmFusedArgs &a, int n_cu, hipStream_t s) {
+// workgroup size (a multiple of 64, <= APM_FUSED_MAX_THREADS) and workgroups per CU that put the most waves on a CU
+int apm_fused_geometry(const ApmFusedArgs &a, int *threads) {
+    const void *fn = apm_fused_fn(a.v.band, a.s.stride);
+    int best_waves = 0, best_blocks = 0;
+    *threads = 0;
+    if (!fn) return 0;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const int forced = getenv("APM_FUSED_THREADS") ? atoi(getenv("APM_FUSED_THREADS")) : 0; // (A/B aid)
+    for (int t = APM_FUSED_MAX_THREADS; t >= 256; t -= 64) {
+        if (forced && t != forced) continue;
+        const size_t lds = apm_fused_lds_bytes(a, t);
+        if (lds > (size_t)160 * 1024) continue;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, t, lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            continue;
+        }
+        if (per_cu * (t / 64) > best_waves) { // (ties: the bigger workgroup, fewer copies of the tables)
+            best_waves = per_cu * (t / 64);
+            best_blocks = per_cu;
+            *threads = t;
+        }
+    }
+    return best_blocks;
+}
+
+hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, hipStream_t s) {
     if (a.s.nchunks <= 0 || a.v.n_pats <= 0) return hipSuccess;
-    const void *fn = nullptr;
-    switch (a.v.band) {
-    case 0: fn = (const void *)apm_fused_kernel<0>; break;
-    case 1: fn = (const void *)apm_fused_kernel<1>; break;
-    case 2: fn = (const void *)apm_fused_kernel<2>; break;
-    case 3: fn = (const void *)apm_fused_kernel<3>; break;
-    default: return hipErrorInvalidValue;
-    }
-    const size_t lds = apm_fused_lds_bytes(a);
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int64_t want = (a.s.nchunks + 4 * (APM_FUSED_BLOCK / 64) - 1) / (4 * (APM_FUSED_BLOCK / 64));
-    const int64_t nb = want < n_cu ? want : n_cu; // one 1024-thread workgroup per CU
+    const void *fn = apm_fused_fn(a.v.band, a.s.stride);
+    if (!fn || threads < 64 || threads > APM_FUSED_MAX_THREADS || (threads & 63)) return hipErrorInvalidValue;
+    const size_t lds = apm_fused_lds_bytes(a, threads);
+    const int64_t n_fb = (a.s.nchunks + 3) / 4, want = (n_fb + threads / 64 - 1) / (threads / 64);
+    const int64_t nb = want < max_blocks ? want : (max_blocks < 1 ? 1 : max_blocks);
     ApmFusedArgs args = a;
     args.s.n_main_blocks = (int)nb;
+    args.v.n_blocks = (int)nb;
+#ifdef APM_MEASURE
+    if (const char *e = getenv("APM_MEASURE_SKIP")) args.v.skip_mask = atoi(e);
+#endif
     void *kargs[] = {&args};
-    return hipLaunchKernel(fn, dim3((unsigned)(nb + a.s.n_tail)), dim3(APM_FUSED_BLOCK), kargs, lds, s);
+    return hipLaunchKernel(fn, dim3((unsigned)(nb + a.s.n_tail)), dim3((unsigned)threads), kargs, lds, s);
 }

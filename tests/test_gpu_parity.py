@@ -761,6 +761,22 @@ for name, alphabet, n in (("dna", b"ACGT", 300000), ("prose", b"etaoin shrdlucET
             ctx.set_patterns(pats, k)
             out["%s:%d" % (name, k)] = dict(patterns=[p.decode("latin-1") for p in pats], counts=ctx.count_buffer(bytes(text)),
                                             kernels=[ctx.pattern_kernel(i) for i in range(len(pats))])
+    for k in (2, 3, 4):   # long pieces only (>= 15 bytes): the sampled (stride-8) sieve
+        pats = []
+        for m in (80, 96, 100, 128):
+            o = rng.randrange(0, len(text) - m)
+            p = bytearray(text[o:o + m])
+            for _ in range(rng.randrange(0, k - 1)):           # <= k - 2 substitutions
+                p[rng.randrange(m)] = rng.choice(alphabet)
+            if rng.random() < 0.5:                               # + one deletion and one insertion: still within k
+                i, j = sorted(rng.sample(range(1, m - 1), 2))
+                del p[i]; p.insert(j, rng.choice(alphabet))
+            pats.append(bytes(p))
+        with apm.ApmContext(device=0) as ctx:
+            ctx.set_patterns(pats, k)
+            out["%s:%d:long" % (name, k)] = dict(patterns=[p.decode("latin-1") for p in pats], counts=ctx.count_buffer(bytes(text)),
+                                                 kernels=[ctx.pattern_kernel(i) for i in range(len(pats))],
+                                                 stride=ctx.stat("sieve_stride"), fused=ctx.stat("sieve_fused"))
 print(json.dumps(out))
 """
 
@@ -768,7 +784,8 @@ print(json.dumps(out))
 @pytest.mark.parametrize("env", [{}, {"APM_FILTER_STREAM": "0"}, {"APM_FILTER_STREAM": "2"}, {"APM_FILTER_STREAM": "3"},
                                  {"APM_FILTER_DMA": "0"}, {"APM_FILTER_STREAM": "2", "APM_FILTER_DMA": "0"},
                                  {"APM_SIEVE": "0"}, {"APM_SIEVE": "0", "APM_FILTER_STREAM": "2"},
-                                 {"APM_FUSED": "1"}],         # sieve + verify fused into one kernel (text staged per wave in LDS)
+                                 {"APM_FUSED": "1"},          # sieve + verify in one kernel for every sieved set (default: sampled sets only)
+                                 {"APM_FUSED": "0"}],         # ... for none
                          ids=lambda e: ",".join("%s=%s" % (k[4:], v) for k, v in e.items()) or "default")
 def test_every_filter_kernel_form_agrees_with_oracle(env):
     """The BANDED path picks between the LDS-tile kernel (LDS-DMA or register-staged) and the wave-autonomous
@@ -782,14 +799,16 @@ def test_every_filter_kernel_form_agrees_with_oracle(env):
     for name, alphabet, n in (("dna", b"ACGT", 300000), ("prose", b"etaoin shrdlucETAOIN\n.,", 200000)):
         trng = random.Random(name)
         texts[name] = bytes(bytearray(trng.choice(alphabet) for _ in range(n)))
-    assert len(got) == 8
+    assert len(got) == 14
     for key, res in got.items():
-        name, k = key.split(":")
+        name, k = key.split(":")[:2]
+        if key.endswith(":long") and env.get("APM_SIEVE") != "0":
+            assert res["stride"] == 8 and res["fused"] == (0 if env.get("APM_FUSED") == "0" else 1), (key, env, res["stride"], res["fused"])
         pats = [p.encode("latin-1") for p in res["patterns"]]
         for p, kern in zip(pats, res["kernels"]):
             assert kern == (4 if len(p) // (int(k) + 1) >= 4 else 3), "BANDED wherever the pieces are long enough"
         assert res["counts"] == H.oracle_counts(texts[name], pats, int(k), banded=True), (key, env)
-        assert sum(res["counts"]) >= 5
+        assert sum(res["counts"]) >= (4 if key.endswith(":long") else 5)
 
 
 @pytest.mark.parametrize("m,k", [(16, 3), (20, 3), (36, 3), (50, 5), (24, 2)])
@@ -927,6 +946,8 @@ def test_sieve_pipeline_vs_full_dp_at_scale(apm, seed):
             c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())
             c2.synchronize()
             got[variant] = cnt.cpu().tolist()
+            if variant == "auto" and "APM_FUSED" not in os.environ:
+                assert c2.stat("sieve_fused") == (1 if sampled else 0)   # sampled sets run sieve + verify as one kernel
         assert got["auto"] == got["bitpar"], (seed, k, sampled, [len(p) for p in pats])
         assert sum(got["auto"]) >= len(pats) // 2
 
