@@ -742,6 +742,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
 import helpers as H
 apm = H.pkg()
 rng = random.Random(20241)
+lrng = random.Random(777)   # (its own stream: the mixed sets stay what they were)
 out = {}
 for name, alphabet, n in (("dna", b"ACGT", 300000), ("prose", b"etaoin shrdlucETAOIN\n.,", 200000)):
     trng = random.Random(name)                              # the parent regenerates the text from this seed
@@ -764,13 +765,13 @@ for name, alphabet, n in (("dna", b"ACGT", 300000), ("prose", b"etaoin shrdlucET
     for k in (2, 3, 4):   # long pieces only (>= 15 bytes): the sampled (stride-8) sieve
         pats = []
         for m in (80, 96, 100, 128):
-            o = rng.randrange(0, len(text) - m)
+            o = lrng.randrange(0, len(text) - m)
             p = bytearray(text[o:o + m])
-            for _ in range(rng.randrange(0, k - 1)):           # <= k - 2 substitutions
-                p[rng.randrange(m)] = rng.choice(alphabet)
-            if rng.random() < 0.5:                               # + one deletion and one insertion: still within k
-                i, j = sorted(rng.sample(range(1, m - 1), 2))
-                del p[i]; p.insert(j, rng.choice(alphabet))
+            for _ in range(lrng.randrange(0, k - 1)):           # <= k - 2 substitutions
+                p[lrng.randrange(m)] = lrng.choice(alphabet)
+            if lrng.random() < 0.5:                               # + one deletion and one insertion: still within k
+                i, j = sorted(lrng.sample(range(1, m - 1), 2))
+                del p[i]; p.insert(j, lrng.choice(alphabet))
             pats.append(bytes(p))
         with apm.ApmContext(device=0) as ctx:
             ctx.set_patterns(pats, k)
