@@ -160,6 +160,8 @@ struct DeviceState {
     uint32_t *d_masks = nullptr;               // the sieve's hit masks: one dword per lane and 4 KiB block (n / 16 bytes)
     size_t masks_cap = 0;                      // dwords
     int64_t last_mask_blocks = 0;              // blocks the last call's sieve wrote (statistics)
+    uint32_t *d_work = nullptr;                // block-distribution counters of the verify / fused launches (ApmVerifyArgs::work)
+    int work_epoch = 0;
     unsigned long long *d_stats = nullptr;     // 8 counters (statistics kernel; measurement build: verify counters)
     bool last_fused = false;                   // the last call used the fused form of the pipeline
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
@@ -1030,6 +1032,11 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
         const int64_t p_lo = std::max<int64_t>(0, jb - band) & ~(int64_t)15;
         const int64_t p_hi = std::min<int64_t>(avail, je + ctx->sieve.m_max + band);
         if (p_hi > p_lo && avail_pad >= 16 && avail_pad < ((int64_t)1 << 32) - 4096) {
+            if (!ds.d_work) {
+                HIP_TRY(ctx, hipMalloc((void **)&ds.d_work, APM_WORK_BYTES));
+                HIP_TRY(ctx, hipMemsetAsync(ds.d_work, 0, APM_WORK_BYTES, ds.stream));
+                ds.work_epoch = 0;
+            }
             // FUSED form: one kernel per verify group sieves and verifies; the text leaves HBM once, no masks.  Measured on
             // MI355X (profiles/r02/fused_ab.txt): the sampled pipeline gains 15 % (cfg4 0.268 -> 0.228 ms per GiB: its
             // sieve is a few instructions per KiB, the verification hides behind the stream), the per-position one is
@@ -1077,7 +1084,7 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 va.code_shift = ctx->sieve.code_shift;
                 va.stride = ctx->sieve.stride;
 #ifdef APM_MEASURE
-                if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, 64));
+                if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, APM_STATS_BYTES));
                 va.stats = ds.d_stats;
 #endif
                 if (!V.fused_threads) {
@@ -1096,9 +1103,10 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                     }
                     const VerifyLaunch &V = ctx->sieve.launches[fa_index[&fa - fargs.data()]];
 #ifdef APM_MEASURE
-                    HIP_TRY(ctx, hipMemsetAsync(ds.d_stats, 0, 64, ds.stream));
+                    HIP_TRY(ctx, hipMemsetAsync(ds.d_stats, 0, APM_STATS_BYTES, ds.stream));
 #endif
-                    HIP_TRY(ctx, apm_launch_fused(fa, V.fused_threads, ds.n_cu * V.fused_blocks_per_cu, ds.stream));
+                    fa.v.work = ds.d_work;
+                    HIP_TRY(ctx, apm_launch_fused(fa, V.fused_threads, ds.n_cu * V.fused_blocks_per_cu, &ds.work_epoch, ds.stream));
                     { const int nrc = note_launch(ctx, ds, "fused"); if (nrc) return nrc; }
                 }
                 fused_run = true;
@@ -1168,12 +1176,13 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
                 va.tile0 = p_lo;
                 va.n_mask_blocks = n_mask_blocks;
 #ifdef APM_MEASURE
-                if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, 64));
-                HIP_TRY(ctx, hipMemsetAsync(ds.d_stats, 0, 64, ds.stream));
+                if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, APM_STATS_BYTES));
+                HIP_TRY(ctx, hipMemsetAsync(ds.d_stats, 0, APM_STATS_BYTES, ds.stream));
                 va.stats = ds.d_stats;
 #endif
+                va.work = ds.d_work;
                 if (!V.blocks_per_cu) V.blocks_per_cu = apm_verify_geometry(va, &V.threads);
-                HIP_TRY(ctx, apm_launch_verify(va, V.threads, ds.n_cu * V.blocks_per_cu, ds.stream));
+                HIP_TRY(ctx, apm_launch_verify(va, V.threads, ds.n_cu * V.blocks_per_cu, &ds.work_epoch, ds.stream));
                 { const int nrc = note_launch(ctx, ds, "verify"); if (nrc) return nrc; }
             }
             sieve_run = true;
@@ -1606,6 +1615,7 @@ void apm_destroy(apm_ctx *ctx) {
         if (ds.d_text) hipFree(ds.d_text);
         if (ds.d_masks) hipFree(ds.d_masks);
         if (ds.d_stats) hipFree(ds.d_stats);
+        if (ds.d_work) hipFree(ds.d_work);
         for (hipEvent_t e : ds.ev_stage) if (e) hipEventDestroy(e);
         for (hipEvent_t e : ds.ev_launch) if (e) hipEventDestroy(e);
         for (hipEvent_t e : {ds.ev_start, ds.ev_kstart, ds.ev_mstart, ds.ev_mstop, ds.ev_stop}) if (e) hipEventDestroy(e);
@@ -1946,7 +1956,7 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
         *value = 0;
         if (!ds.d_masks || ds.last_mask_blocks <= 0) return APM_OK;
         HIP_TRY(ctx, hipSetDevice(ds.dev));
-        if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, 64));
+        if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, APM_STATS_BYTES));
         unsigned long long *d_sum = ds.d_stats + 7;
         HIP_TRY(ctx, hipMemsetAsync(d_sum, 0, 8, ds.stream));
         hipLaunchKernelGGL(apm_popcount_kernel, dim3(1024), dim3(256), 0, ds.stream, ds.d_masks, (unsigned long long)ds.last_mask_blocks * 64ull, d_sum);
@@ -1965,6 +1975,38 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
         if (n == "verify_survivors") { *value = (double)h[1]; return APM_OK; }
         if (n == "verify_dp_items") { *value = (double)h[2]; return APM_OK; }
         if (n == "verify_counted") { *value = (double)h[3]; return APM_OK; }
+        if (n.rfind("verify_wave_", 0) == 0) { // per-wave start / end stamps (APM_MEASURE_SKIP bit 9), in us from the first start
+            std::vector<unsigned long long> t(2 * APM_STATS_WAVES);
+            HIP_TRY(ctx, hipMemcpy(t.data(), ds.d_stats + 8, t.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> st, en;
+            unsigned long long t0 = ~0ull;
+            for (size_t w = 0; w < APM_STATS_WAVES; ++w) if (t[2 * w + 1]) t0 = std::min(t0, t[2 * w]);
+            for (size_t w = 0; w < APM_STATS_WAVES; ++w) if (t[2 * w + 1]) { st.push_back((double)(t[2 * w] - t0) * 0.01); en.push_back((double)(t[2 * w + 1] - t0) * 0.01); }
+            if (n.rfind("verify_wave_grp", 0) == 0 || n.rfind("verify_wave_xcd", 0) == 0) { // verify_wave_grpmax<g> / grpmin<g> / xcdavg<x>: end stamps by group / by blockIdx % 8
+                const bool by_xcd = n[12] == 'x';
+                const int want = atoi(n.c_str() + 18);
+                double lo = 1e30, hi = 0, sum = 0; long cnt = 0;
+                for (size_t w = 0; w < APM_STATS_WAVES; ++w) {
+                    if (!t[2 * w + 1]) continue;
+                    const int key = by_xcd ? (int)((w / 4) % 8) : (int)((w ^ (w >> 5)) % APM_WORK_GROUPS);
+                    if (key != want) continue;
+                    const double e = (double)(t[2 * w + 1] - t0) * 0.01;
+                    lo = std::min(lo, e); hi = std::max(hi, e); sum += e; ++cnt;
+                }
+                *value = n[15] == 'm' && n[16] == 'a' ? hi : (n[15] == 'm' && n[16] == 'i' ? lo : (cnt ? sum / cnt : 0));
+                return APM_OK;
+            }
+            if (en.empty()) { *value = 0; return APM_OK; }
+            std::sort(st.begin(), st.end());
+            std::sort(en.begin(), en.end());
+            if (n == "verify_wave_count") { *value = (double)en.size(); return APM_OK; }
+            if (n == "verify_wave_start_max") { *value = st.back(); return APM_OK; }
+            if (n == "verify_wave_end_min") { *value = en.front(); return APM_OK; }
+            if (n == "verify_wave_end_p10") { *value = en[en.size() / 10]; return APM_OK; }
+            if (n == "verify_wave_end_p50") { *value = en[en.size() / 2]; return APM_OK; }
+            if (n == "verify_wave_end_p90") { *value = en[en.size() * 9 / 10]; return APM_OK; }
+            if (n == "verify_wave_end_max") { *value = en.back(); return APM_OK; }
+        }
     }
 #endif
     return fail(ctx, APM_ERR_INVALID, "unknown statistic '%s'", name);

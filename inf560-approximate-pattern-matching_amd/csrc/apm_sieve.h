@@ -67,6 +67,11 @@ struct ApmVerifyArgs {
     int64_t tile0;              /* relative position of block 0 */
     int64_t n_mask_blocks;      /* 4 KiB blocks the sieve wrote masks for */
     int n_blocks;               /* set by the launcher */
+    /* dynamic block distribution (apm_verify_body): two sets of APM_WORK_GROUPS counters, APM_WORK_STRIDE dwords apart, all
+       zero before the first launch; launch e uses set e & 1 and zeroes the other for launch e + 1 (same stream) */
+    uint32_t *work;
+    int work_epoch;
+    int work_groups;            /* set by the launcher: min(APM_WORK_GROUPS, waves of the launch) */
 #ifdef APM_MEASURE
     int skip_mask;
     unsigned long long *stats;  /* [0] pre-check evaluations, [1] survivors, [2] DP items run, [3] windows counted */
@@ -83,12 +88,17 @@ struct ApmFusedArgs {
     ApmVerifyArgs v;
 };
 #define APM_FUSED_MAX_THREADS 896 /* 14 waves: two workgroups put 7 waves on every SIMD */
-hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, hipStream_t s);
+hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, int *work_epoch, hipStream_t s);
 size_t apm_fused_lds_bytes(const ApmFusedArgs &a, int threads);
 int apm_fused_geometry(const ApmFusedArgs &a, int *threads); /* workgroups per CU; *threads = workgroup size (0: does not fit) */
 
+#define APM_WORK_GROUPS 32
+#define APM_WORK_STRIDE 64
+#define APM_WORK_BYTES (2 * APM_WORK_GROUPS * APM_WORK_STRIDE * 4)
+#define APM_STATS_WAVES 16384                         /* measurement build: per-wave time stamps behind the 8 counters */
+#define APM_STATS_BYTES (64 + 16 * APM_STATS_WAVES)
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s);
-hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, hipStream_t s);
+hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, int *work_epoch, hipStream_t s);
 int apm_verify_geometry(const ApmVerifyArgs &a, int *threads); /* workgroups per CU; *threads = 256 or 512 */
 
 #endif /* APM_SIEVE_H */

@@ -18,9 +18,16 @@
  * Both need a 16-byte aligned text pointer and a shard of < 4 GiB; the runtime falls back to the LDS-tile
  * kernels of apm_kernels.hip otherwise.
  */
+#include <algorithm>
 #include "apm_device.h"
 #include "apm_sieve.h"
 
+#ifndef APM_WORK_CH
+#define APM_WORK_CH 2u /* blocks per chunk of the dynamic distribution (per-position sets) */
+#endif
+#ifndef APM_WORK_HASH
+#define APM_WORK_HASH 1
+#endif
 #ifndef APM_FUSED_PIPE
 #define APM_FUSED_PIPE 1 /* the same for the fused form */
 #endif
@@ -323,7 +330,7 @@ struct ApmVerifyCore {
         wj = (uint32_t)j;
         word = (uint32_t)(kunit * NSH + dl + BAND);
 #ifdef APM_MEASURE
-        atomicAdd(&a.stats[2], 1ull);
+        if (APM_SKIP(a, 256)) atomicAdd(&a.stats[2], 1ull); // (bit 8 = collect the statistics: one atomic per DP item distorts the timing)
 #endif
         return apm_banded_verify<BAND>(ApmBufText{rs, (uint32_t)j}, s_pat, poff, m, a.k);
     }
@@ -363,7 +370,7 @@ struct ApmVerifyCore {
             if (!__builtin_amdgcn_ballot_w64(earlier) && lane == 0) {
                 atomicAdd(&s_cnt[bpat], 1u);
 #ifdef APM_MEASURE
-                atomicAdd(&a.stats[3], 1ull);
+                if (APM_SKIP(a, 256)) atomicAdd(&a.stats[3], 1ull);
 #endif
             }
         }
@@ -424,28 +431,66 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     // blocks (one dword per lane and block) into a queue of positions and takes 64 of them per batch -- dense lanes
     // across block borders, since the text comes from global memory anyway
     constexpr uint32_t STEP = SAMPLED ? 8u : 2u; // bytes between two lookups of the sieve
-    const uint32_t n_waves = (uint32_t)a.n_blocks * (uint32_t)(THREADS / 64), my_wave = blockIdx.x * (uint32_t)(THREADS / 64) + (uint32_t)wv;
-    uint64_t bi = FUSED ? 0 : ((uint64_t)a.n_mask_blocks * my_wave) / n_waves;
-    const uint64_t b_end = FUSED ? 0 : ((uint64_t)a.n_mask_blocks * (my_wave + 1u)) / n_waves;
+    const uint32_t my_wave = blockIdx.x * (uint32_t)(THREADS / 64) + (uint32_t)wv;
+    // ---- which blocks a wave works on: DYNAMIC.  Equal static runs left the waves finishing anywhere between 0.45 and
+    // 1.0 of the kernel's duration (per-wave time stamps, measurement build).  The blocks form chunks of CH; the chunks
+    // are split into APM_WORK_GROUPS contiguous ranges, each with its own counter (a single one would serialise: ~90
+    // atomics per microsecond chip-wide); wave w belongs to group w % APM_WORK_GROUPS -- every group is a sample of the
+    // whole machine, so the groups finish together -- and takes the group's next chunk with one atomic, issued a
+    // chunk ahead of its use.  The counters of the NEXT launch are zeroed here (two sets, the host alternates). ----
+    constexpr uint32_t CH = SAMPLED ? 8u : APM_WORK_CH;
+    const uint32_t NB = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : (uint32_t)a.n_mask_blocks; // 4 KiB blocks in all
+    const uint32_t NC = (NB + CH - 1u) / CH;
+    // NG = min(APM_WORK_GROUPS, waves of the launch): no group without a wave.  Workgroups go round the XCDs, so the low
+    // bits of the wave number alone would tie a group to one XCD and one wave slot: fold the higher bits in
+    const uint32_t NG = (uint32_t)a.work_groups, grp = (APM_WORK_HASH ? (my_wave ^ (my_wave >> 5)) : my_wave) % NG;
+    const uint32_t f_g = (uint32_t)(((uint64_t)NC * grp) / NG), n_g = (uint32_t)(((uint64_t)NC * (grp + 1u)) / NG) - f_g;
+    uint32_t *const ctr = a.work + ((uint32_t)a.work_epoch & 1u) * (APM_WORK_GROUPS * APM_WORK_STRIDE) + grp * APM_WORK_STRIDE;
+    if (blockIdx.x == 0 && tid < APM_WORK_GROUPS) a.work[(((uint32_t)a.work_epoch + 1u) & 1u) * (APM_WORK_GROUPS * APM_WORK_STRIDE) + (uint32_t)tid * APM_WORK_STRIDE] = 0u;
+    auto grab = [&]() __attribute__((always_inline)) -> uint32_t { // (lane 0 holds the answer; read with readfirstlane when it is needed)
+        return lane == 0 ? __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    };
+    uint32_t grab_v = grab();
+    uint32_t it_b = 0, it_end = 0; // the chunk in hand: blocks [it_b, it_end)
+    bool it_done = false;
+    auto it_next = [&](uint32_t &b) __attribute__((always_inline)) -> bool { // wave-uniform: the wave's next block
+        if (it_b >= it_end) {
+            if (it_done) return false;
+            const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)grab_v);
+            if (i >= n_g) { it_done = true; return false; } // every wave gets here: its group's range is exhausted
+            it_b = (f_g + i) * CH;
+            it_end = it_b + CH < NB ? it_b + CH : NB;
+            grab_v = grab();
+        }
+        b = it_b++;
+        return true;
+    };
     // masks of the block in hand and of the AHEAD blocks after it (sparse sampled lists are bound by this chain of loads)
     constexpr int AHEAD = FUSED ? 1 : (SAMPLED ? 4 : 1);
-    uint32_t hm = 0, hm_q[AHEAD];
+    constexpr uint32_t NONE = 0xffffffffu;
+    uint32_t hm = 0, hm_q[AHEAD], hb_q[AHEAD]; // hb_q: their block numbers (wave-uniform)
     if constexpr (!FUSED) {
 #pragma unroll
-        for (int i = 0; i < AHEAD; ++i) hm_q[i] = bi + (uint64_t)i < b_end ? a.masks[(bi + (uint64_t)i) * 64 + (uint64_t)lane] : 0u;
+        for (int i = 0; i < AHEAD; ++i) {
+            uint32_t b = NONE;
+            hb_q[i] = it_next(b) ? b : NONE;
+            hm_q[i] = hb_q[i] != NONE ? a.masks[(uint64_t)hb_q[i] * 64 + (uint64_t)lane] : 0u;
+        }
     }
+#ifdef APM_MEASURE
+    if (APM_SKIP(a, 512) && lane == 0 && my_wave < APM_STATS_WAVES) a.stats[8 + 2 * my_wave] = wall_clock64();
+#endif
     uint32_t blk = 0;    // relative position of the block in hand
     uint32_t qcount = 0; // wave-uniform
-    // FUSED: the wave's blocks are my_wave, my_wave + n_waves, ... (neighbouring waves stream neighbouring blocks)
-    uint32_t fb = my_wave;
-    const uint32_t n_fb = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : 0u, nch32 = FUSED ? (uint32_t)sv->nchunks : 0u;
+    const uint32_t nch32 = FUSED ? (uint32_t)sv->nchunks : 0u;
     const uint32_t tile0 = FUSED ? (uint32_t)sv->tile0 : 0u;
     uint32_t pf = 0; // one byte per 64 of the wave's NEXT block, loaded only to have its lines on their way (kept alive below)
     auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
     // hit mask of this lane for the block at relative position b0 (see ApmSieve2Args::masks for the bit layout)
-    auto sieve_block = [&](uint32_t b0) __attribute__((always_inline)) -> uint32_t {
+    auto sieve_block = [&](uint32_t b0, uint32_t fb) __attribute__((always_inline)) -> uint32_t {
         const uint32_t g = b0 + 16u * (uint32_t)lane, c0 = fb * 4u;
-        const uint32_t nxt = fb + n_waves < n_fb ? b0 + n_waves * 4096u + 64u * (uint32_t)lane : 0xfffffff0u;
+        // (the chunk's next block; the first block of a chunk comes without this help)
+        const uint32_t nxt = it_b < it_end ? tile0 + it_b * 4096u + 64u * (uint32_t)lane : 0xfffffff0u;
         uint32_t out = 0;
         if constexpr (SAMPLED) { // one lookup per 8 bytes in the image's bitmap over 16-bit code words (apm_sieve8_kernel)
             u32x4 r[4];
@@ -497,19 +542,22 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
         while (qcount < 64u) {
             if (!__builtin_amdgcn_ballot_w64(hm != 0u)) { // block done: take the prefetched masks of the next one
                 if constexpr (FUSED) { // ... or sieve the wave's next block
-                    if (fb >= n_fb) break;
-                    blk = tile0 + fb * 4096u;
-                    hm = sieve_block(blk);
-                    fb += n_waves;
+                    uint32_t b;
+                    if (!it_next(b)) break;
+                    blk = tile0 + b * 4096u;
+                    hm = sieve_block(blk, b);
                     continue;
                 }
-                if (bi >= b_end) break;
-                blk = (uint32_t)(a.tile0 + (int64_t)bi * 4096);
+                if (hb_q[0] == NONE) break;
+                blk = (uint32_t)(a.tile0 + (int64_t)hb_q[0] * 4096);
                 hm = hm_q[0];
 #pragma unroll
-                for (int i = 0; i + 1 < AHEAD; ++i) hm_q[i] = hm_q[i + 1];
-                ++bi;
-                hm_q[AHEAD - 1] = bi + (uint64_t)(AHEAD - 1) < b_end ? a.masks[(bi + (uint64_t)(AHEAD - 1)) * 64 + (uint64_t)lane] : 0u;
+                for (int i = 0; i + 1 < AHEAD; ++i) { hm_q[i] = hm_q[i + 1]; hb_q[i] = hb_q[i + 1]; }
+                {
+                    uint32_t b = NONE;
+                    hb_q[AHEAD - 1] = it_next(b) ? b : NONE;
+                    hm_q[AHEAD - 1] = hb_q[AHEAD - 1] != NONE ? a.masks[(uint64_t)hb_q[AHEAD - 1] * 64 + (uint64_t)lane] : 0u;
+                }
                 continue;
             }
             const bool has = hm != 0u;
@@ -620,7 +668,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
 #endif
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
 #ifdef APM_MEASURE
-        if (mask && lane == 0) atomicAdd(&a.stats[1], (unsigned long long)__builtin_popcountll(mask));
+        if (APM_SKIP(a, 256) && mask && lane == 0) atomicAdd(&a.stats[1], (unsigned long long)__builtin_popcountll(mask));
 #endif
         if (mask) { // survivors -> the wave's list (ballot + mbcnt, no atomics); at most FLUSH_AT - 1 + 64 entries
             const uint32_t idx = n_surv + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -641,6 +689,9 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     }
 
     asm volatile("" ::"v"(pf));
+#ifdef APM_MEASURE
+    if (APM_SKIP(a, 512) && lane == 0 && my_wave < APM_STATS_WAVES) a.stats[9 + 2 * my_wave] = wall_clock64();
+#endif
     __syncthreads();
     for (int i = tid; i < a.n_pats; i += THREADS) {
         const uint32_t cnt = s_cnt[i];
@@ -700,15 +751,18 @@ int apm_verify_geometry(const ApmVerifyArgs &a, int *threads) {
     return best_blocks;
 }
 
-hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, hipStream_t s) {
+hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, int *work_epoch, hipStream_t s) {
     if (a.n_pats <= 0) return hipSuccess;
     const void *fn = apm_verify_fn(a.band, threads, a.stride);
     if (!fn) return hipErrorInvalidValue;
     ApmVerifyArgs args = a;
     args.n_blocks = max_blocks < 1 ? 1 : max_blocks; // (number of hits unknown on the host: a persistent grid shares the blocks)
 #ifdef APM_MEASURE
+    if (const char *e = getenv("APM_VERIFY_GRID_PCT")) args.n_blocks = std::max(1, (int)((long)args.n_blocks * atoi(e) / 100)); // occupancy sensitivity
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
 #endif
+    args.work_groups = std::min<long>(APM_WORK_GROUPS, (long)args.n_blocks * (threads / 64));
+    args.work_epoch = (*work_epoch)++; // (only launches that run advance it: each zeroes the counter set of the next)
     void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)args.n_blocks), dim3((unsigned)threads), kargs, apm_verify_lds_bytes_t(a, threads), s);
 }
@@ -717,7 +771,7 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
 // FUSED: sieve + verify in one launch (apm_verify_body<.., FUSED = true>; see ApmFusedArgs)
 // ---------------------------------------------------------------------------
 template <int BAND, bool SAMPLED>
-__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND <= 1 ? 7 : 6) : 5) void apm_fused_kernel(ApmFusedArgs f) {
+__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND <= 1 ? 7 : (BAND == 2 ? 6 : 5)) : 5) void apm_fused_kernel(ApmFusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if ((int)blockIdx.x >= f.s.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
         apm_tail_body(f.s.tail, (int)blockIdx.x - f.s.n_main_blocks, reinterpret_cast<uint4 *>(smem), (int)threadIdx.x);
@@ -748,7 +802,11 @@ int apm_fused_geometry(const ApmFusedArgs &a, int *threads) {
     *threads = 0;
     if (!fn) return 0;
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const int forced = getenv("APM_FUSED_THREADS") ? atoi(getenv("APM_FUSED_THREADS")) : 0; // (A/B aid)
+#ifdef APM_MEASURE
+    static const int forced = getenv("APM_FUSED_THREADS") ? atoi(getenv("APM_FUSED_THREADS")) : 0;
+#else
+    constexpr int forced = 0;
+#endif
     for (int t = APM_FUSED_MAX_THREADS; t >= 256; t -= 64) {
         if (forced && t != forced) continue;
         const size_t lds = apm_fused_lds_bytes(a, t);
@@ -767,7 +825,7 @@ int apm_fused_geometry(const ApmFusedArgs &a, int *threads) {
     return best_blocks;
 }
 
-hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, hipStream_t s) {
+hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, int *work_epoch, hipStream_t s) {
     if (a.s.nchunks <= 0 || a.v.n_pats <= 0) return hipSuccess;
     const void *fn = apm_fused_fn(a.v.band, a.s.stride);
     if (!fn || threads < 64 || threads > APM_FUSED_MAX_THREADS || (threads & 63)) return hipErrorInvalidValue;
@@ -780,6 +838,8 @@ hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, 
 #ifdef APM_MEASURE
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.v.skip_mask = atoi(e);
 #endif
+    args.v.work_groups = (int)std::min<int64_t>(APM_WORK_GROUPS, nb * (threads / 64));
+    args.v.work_epoch = (*work_epoch)++;
     void *kargs[] = {&args};
     return hipLaunchKernel(fn, dim3((unsigned)(nb + a.s.n_tail)), dim3((unsigned)threads), kargs, lds, s);
 }
