@@ -25,6 +25,12 @@
 #ifndef APM_WORK_CH
 #define APM_WORK_CH 2u /* blocks per chunk of the dynamic distribution (per-position sets) */
 #endif
+#ifndef APM_WORK_CH8
+#define APM_WORK_CH8 8u /* ... sampled sets */
+#endif
+#ifndef APM_FUSED_NBLK
+#define APM_FUSED_NBLK 2u /* fused sampled form: blocks per sieve step (1, 2 or 4) */
+#endif
 #ifndef APM_WORK_HASH
 #define APM_WORK_HASH 1
 #endif
@@ -60,23 +66,35 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSiev
     const int64_t W = (int64_t)a.n_main_blocks * (APM_SIEVE2_BLOCK / 64);
     const int64_t nch = a.nchunks;
 
-    auto load_chunk = [&](int64_t cc, u32x4 &r, v2u32 &e) __attribute__((always_inline)) {
+    // 16 bytes per lane and chunk; `tl`: the 8 bytes behind the chunk (one address for the whole wave).  Chunks behind the
+    // scanned range are loaded all the same -- text or, beyond avail_pad, zeros without traffic -- because the windows of
+    // the last valid chunk run into them; only their own hits are dropped.
+    auto load_chunk = [&](int64_t cc, u32x4 &r) __attribute__((always_inline)) {
         const int64_t g = a.tile0 + cc * 1024;
-        const int64_t lim = cc < nch ? a.avail_pad - g : 0; // chunks past the end: zero records -> zeros, no traffic
-        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1040 ? 1040u : (uint32_t)lim);
+        const int64_t lim = a.avail_pad - g;
+        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1024 ? 1024u : (uint32_t)lim);
         const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (lim > 0 ? g : 0), 0, (int)nrec, 0x00020000);
         r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
-        e = __builtin_amdgcn_raw_buffer_load_b64(rs, 16 * lane + 16, 0, 0);
+    };
+    auto load_tail = [&](int64_t cc, v2u32 &tl) __attribute__((always_inline)) { // the 8 bytes at the start of chunk cc
+        const int64_t g = a.tile0 + cc * 1024;
+        const int64_t lim = a.avail_pad - g;
+        const uint32_t nrec = lim <= 0 ? 0u : (lim > 8 ? 8u : (uint32_t)lim);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (lim > 0 ? g : 0), 0, (int)nrec, 0x00020000);
+        tl = __builtin_amdgcn_raw_buffer_load_b64(rs, 0, 0, 0);
     };
     // 4 bytes -> 8 code bits (byte z in bits 2z..): shift + and + one v_dot4_u32_u8 with the byte weights 1, 4, 16, 64
     const uint32_t cs = (uint32_t)a.code_shift;
     auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
+    auto pack16 = [&](const u32x4 &v) __attribute__((always_inline)) { return pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24); };
     // the bitmap leads this kernel's LDS (no static LDS, checked by the tests): LDS address = the masked code bits
-    // hit mask of the lane's eight even positions: bit 24 + t = position 2t
-    auto hit_bits = [&](const u32x4 &v, const v2u32 &e, int64_t cc) __attribute__((always_inline)) {
-        const uint32_t slo = pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24); // codes of bytes 0..15
-        const uint32_t shi = pack4(e.x) | (pack4(e.y) << 8);                                           // bytes 16..23
+    // hit mask of the lane's eight even positions: bit 24 + t = position 2t.  slo: codes of the lane's 16 bytes; nx0: of the
+    // 8 bytes behind the chunk.  The codes of the 8 bytes behind the LANE's 16 are the low half of the next lane's string:
+    // one DPP move (wave_shl:1; the last lane keeps `old` = nx0) instead of a second load and two more packs.
+    auto hit_bits = [&](uint32_t slo, uint32_t nx0, int64_t cc) __attribute__((always_inline)) {
+        const uint32_t shi = (uint32_t)__builtin_amdgcn_update_dpp((int)nx0, (int)slo, 0x130, 0xf, 0xf, false);
         uint32_t hits = 0;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -93,17 +111,27 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSiev
     };
     int64_t c = ((int64_t)blockIdx.x * (APM_SIEVE2_BLOCK / 64) + wv) * 4; // four neighbouring chunks per wave
     u32x4 r0, r1, r2, r3;
-    v2u32 e0, e1, e2, e3;
-    load_chunk(c, r0, e0);
-    load_chunk(c + 1, r1, e1);
-    load_chunk(c + 2, r2, e2);
-    load_chunk(c + 3, r3, e3);
+    v2u32 tl;
+    load_chunk(c, r0);
+    load_chunk(c + 1, r1);
+    load_chunk(c + 2, r2);
+    load_chunk(c + 3, r3);
+    load_tail(c + 4, tl);
     for (; c < nch; c += 4 * W) {
-        uint32_t h0, h1, h2, h3;
-        { const u32x4 v = r0; const v2u32 e = e0; load_chunk(c + 4 * W, r0, e0); h0 = hit_bits(v, e, c); }
-        { const u32x4 v = r1; const v2u32 e = e1; load_chunk(c + 4 * W + 1, r1, e1); h1 = hit_bits(v, e, c + 1); }
-        { const u32x4 v = r2; const v2u32 e = e2; load_chunk(c + 4 * W + 2, r2, e2); h2 = hit_bits(v, e, c + 2); }
-        { const u32x4 v = r3; const v2u32 e = e3; load_chunk(c + 4 * W + 3, r3, e3); h3 = hit_bits(v, e, c + 3); }
+        const uint32_t s0 = pack16(r0), s1 = pack16(r1), s2 = pack16(r2), s3 = pack16(r3), s4 = pack4(tl.x) | (pack4(tl.y) << 8);
+        load_chunk(c + 4 * W, r0);
+        load_chunk(c + 4 * W + 1, r1);
+        load_chunk(c + 4 * W + 2, r2);
+        load_chunk(c + 4 * W + 3, r3);
+        load_tail(c + 4 * W + 4, tl);
+        // (chunk by chunk: letting the scheduler interleave the 32 lookups costs more registers than the 8 waves per SIMD leave)
+        const uint32_t h0 = hit_bits(s0, (uint32_t)__builtin_amdgcn_readfirstlane((int)s1), c);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t h1 = hit_bits(s1, (uint32_t)__builtin_amdgcn_readfirstlane((int)s2), c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t h2 = hit_bits(s2, (uint32_t)__builtin_amdgcn_readfirstlane((int)s3), c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t h3 = hit_bits(s3, (uint32_t)__builtin_amdgcn_readfirstlane((int)s4), c + 3);
         // the block's hit masks: one coalesced 256-byte store per wave and 4 KiB (see ApmSieve2Args::masks)
         a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = (h0 >> 24) | ((h1 >> 24) << 8) | ((h2 >> 24) << 16) | (h3 & 0xff000000u);
     }
@@ -438,7 +466,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     // atomics per microsecond chip-wide); wave w belongs to group w % APM_WORK_GROUPS -- every group is a sample of the
     // whole machine, so the groups finish together -- and takes the group's next chunk with one atomic, issued a
     // chunk ahead of its use.  The counters of the NEXT launch are zeroed here (two sets, the host alternates). ----
-    constexpr uint32_t CH = SAMPLED ? 8u : APM_WORK_CH;
+    constexpr uint32_t CH = SAMPLED ? APM_WORK_CH8 : APM_WORK_CH;
     const uint32_t NB = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : (uint32_t)a.n_mask_blocks; // 4 KiB blocks in all
     const uint32_t NC = (NB + CH - 1u) / CH;
     // NG = min(APM_WORK_GROUPS, waves of the launch): no group without a wave.  Workgroups go round the XCDs, so the low
@@ -484,26 +512,24 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     uint32_t qcount = 0; // wave-uniform
     const uint32_t nch32 = FUSED ? (uint32_t)sv->nchunks : 0u;
     const uint32_t tile0 = FUSED ? (uint32_t)sv->tile0 : 0u;
-    uint32_t pf = 0; // one byte per 64 of the wave's NEXT block, loaded only to have its lines on their way (kept alive below)
     auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
     // hit mask of this lane for the block at relative position b0 (see ApmSieve2Args::masks for the bit layout)
-    auto sieve_block = [&](uint32_t b0, uint32_t fb) __attribute__((always_inline)) -> uint32_t {
+    // FUSED + SAMPLED: a sieve step takes NBLK neighbouring blocks (a block fills 8 of the 32 mask bits: block i of the step
+    // sits in bits 8 j + 2 i + t) -- twice the bytes in flight per wave; the pass is bound by the latency of these loads
+    constexpr uint32_t NBLK = (FUSED && SAMPLED) ? APM_FUSED_NBLK : 1u;
+    auto sieve_block = [&](uint32_t b0, uint32_t fb, uint32_t nblk) __attribute__((always_inline)) -> uint32_t {
         const uint32_t g = b0 + 16u * (uint32_t)lane, c0 = fb * 4u;
-        // (the chunk's next block; the first block of a chunk comes without this help)
-        const uint32_t nxt = it_b < it_end ? tile0 + it_b * 4096u + 64u * (uint32_t)lane : 0xfffffff0u;
         uint32_t out = 0;
         if constexpr (SAMPLED) { // one lookup per 8 bytes in the image's bitmap over 16-bit code words (apm_sieve8_kernel)
-            u32x4 r[4];
+            u32x4 r[4 * NBLK];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g + 1024u * j), 0, 0);
-            asm volatile("" ::"v"(pf));
-            pf = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)nxt, 0, 0);
+            for (int j = 0; j < (int)(4 * NBLK); ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g + 1024u * j), 0, 0); // (beyond the text: zeros)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < (int)(4 * NBLK); ++j) {
                 const uint32_t slo = pack4(r[j].x) | (pack4(r[j].y) << 8) | (pack4(r[j].z) << 16) | (pack4(r[j].w) << 24);
                 const uint32_t w0 = s_bmp[slo & 2047u], w1 = s_bmp[(slo >> 16) & 2047u];
                 const uint32_t h = ((w0 >> ((slo >> 11) & 31u)) & 1u) | (((w1 >> (slo >> 27)) & 1u) << 1);
-                out |= (c0 + j < nch32 ? h : 0u) << (8 * j);
+                out |= ((c0 + j < nch32 && (uint32_t)(j >> 2) < nblk) ? h : 0u) << (8 * (j & 3) + 2 * (j >> 2));
             }
         } else { // one lookup per even position in the 32 KiB bitmap over 18-bit code words at LDS address 0 (apm_sieve2_kernel)
             // (chunks behind the scanned range are loaded all the same -- text or zeros -- since the windows of the last
@@ -512,8 +538,6 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g + 1024u * j), 0, 0);
             const v2u32 tl = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(b0 + 4096u), 0, 0); // the 8 bytes behind the block
-            asm volatile("" ::"v"(pf));
-            pf = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)nxt, 0, 0);
             uint32_t slo[5]; // codes of the lane's 16 bytes, chunk by chunk; [4]: of the 8 bytes behind the block
 #pragma unroll
             for (int j = 0; j < 4; ++j) slo[j] = pack4(r[j].x) | (pack4(r[j].y) << 8) | (pack4(r[j].z) << 16) | (pack4(r[j].w) << 24);
@@ -545,7 +569,9 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
                     uint32_t b;
                     if (!it_next(b)) break;
                     blk = tile0 + b * 4096u;
-                    hm = sieve_block(blk, b);
+                    uint32_t nblk = 1; // the step's blocks: neighbours out of the same chunk
+                    for (; nblk < NBLK && it_b < it_end; ++nblk) ++it_b;
+                    hm = sieve_block(blk, b, nblk);
                     continue;
                 }
                 if (hb_q[0] == NONE) break;
@@ -565,7 +591,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
             hm &= hm - 1u;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
             const uint32_t idx = qcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (has) s_q[idx] = (blk + (t >> 3) * 1024u + 16u * (uint32_t)lane + (t & 7u) * STEP) / STEP;
+            if (has) s_q[idx] = (blk + (t >> 3) * 1024u + 16u * (uint32_t)lane + (SAMPLED ? (t & 1u) * 8u + ((t >> 1) & 3u) * 4096u : (t & 7u) * 2u)) / STEP;
             qcount += (uint32_t)__builtin_popcountll(mask);
         }
         q = 0;
@@ -688,7 +714,6 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
         }
     }
 
-    asm volatile("" ::"v"(pf));
 #ifdef APM_MEASURE
     if (APM_SKIP(a, 512) && lane == 0 && my_wave < APM_STATS_WAVES) a.stats[9 + 2 * my_wave] = wall_clock64();
 #endif
