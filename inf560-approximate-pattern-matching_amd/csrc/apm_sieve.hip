@@ -796,7 +796,7 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
 // FUSED: sieve + verify in one launch (apm_verify_body<.., FUSED = true>; see ApmFusedArgs)
 // ---------------------------------------------------------------------------
 template <int BAND, bool SAMPLED>
-__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND <= 1 ? 7 : (BAND == 2 ? 6 : 5)) : 5) void apm_fused_kernel(ApmFusedArgs f) {
+__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND <= 1 ? 7 : (BAND == 2 ? 6 : 5)) : (BAND <= 1 ? 6 : 5)) void apm_fused_kernel(ApmFusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if ((int)blockIdx.x >= f.s.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
         apm_tail_body(f.s.tail, (int)blockIdx.x - f.s.n_main_blocks, reinterpret_cast<uint4 *>(smem), (int)threadIdx.x);
