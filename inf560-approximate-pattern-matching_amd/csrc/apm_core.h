@@ -144,8 +144,9 @@ APM_HD bool apm_ext1_core16(const uint32_t (&p)[4], const uint32_t (&t)[5], int 
  * partner pat[poff, poff+plen) that must match the adjoining text within ONE edit, anchored at the exact part and
  * free at its far end (apm_ext1_core16 / apm_ext_fwd semantics); side 0 = no partner.  len may be 0 with side 1:
  * the whole unit is then "partner within one edit from the unit's text position on" (a pair of short pieces).
- * apm_enum_unit_windows calls fn(x) for every 16-bit word x of 2-bit codes (byte z of the window in bits 2z..,
- * code = (byte >> shift) & 3) that the 8 text bytes at the unit's position may show when the unit's predicate holds:
+ * apm_enum_unit_windows calls fn(x) for every word x of 2-bit codes (byte z of the window in bits 2z..,
+ * code = (byte >> shift) & 3) that the W text bytes at the unit's position may show when the unit's predicate holds
+ * (W = 8: the 16-bit words of the verify image; W = 9: the 18-bit words of the sieve's even alignment):
  * a superset is fine (the bitmap is a filter), a missing word would lose matches.
  * ------------------------------------------------------------------------- */
 #if 1 /* host functions (parsed in both passes of a .hip unit) */
@@ -174,11 +175,11 @@ inline bool apm_ext1_visible_ok(const uint8_t *c, int n, const uint8_t *t, int v
 
 /* definition: every continuation of the visible exact part, filtered by apm_ext1_visible_ok */
 template <typename F>
-inline void apm_enum_unit_windows_bruteforce(const uint8_t *pat, const ApmUnit &u, int shift, F fn) {
-    const int vis = u.len < 8 ? u.len : 8, ext = 8 - vis;
+inline void apm_enum_unit_windows_bruteforce(const uint8_t *pat, const ApmUnit &u, int shift, F fn, int W = 8) {
+    const int vis = u.len < W ? u.len : W, ext = W - vis;
     uint32_t x = 0;
     for (int z = 0; z < vis; ++z) x |= (uint32_t)((pat[u.off + z] >> shift) & 3) << (2 * z);
-    uint8_t c[64], t[8];
+    uint8_t c[64], t[9];
     const int n = u.side == 1 ? (u.plen < 64 ? u.plen : 64) : 0;
     for (int i = 0; i < n; ++i) c[i] = (uint8_t)((pat[u.poff + i] >> shift) & 3);
     for (uint32_t p = 0; p < (1u << (2 * ext)); ++p) {
@@ -189,10 +190,10 @@ inline void apm_enum_unit_windows_bruteforce(const uint8_t *pat, const ApmUnit &
 
 /* the same set (or a superset), generated from the edit neighbourhood instead of filtered out of 4^ext words */
 template <typename F>
-inline void apm_enum_unit_windows(const uint8_t *pat, const ApmUnit &u, int shift, F fn) {
-    const int vis = u.len < 8 ? u.len : 8, ext = 8 - vis;
+inline void apm_enum_unit_windows(const uint8_t *pat, const ApmUnit &u, int shift, F fn, int W = 8) {
+    const int vis = u.len < W ? u.len : W, ext = W - vis;
     if (u.side != 1 || ext <= 4) { /* at most 256 continuations: the definition is cheap enough */
-        apm_enum_unit_windows_bruteforce(pat, u, shift, fn);
+        apm_enum_unit_windows_bruteforce(pat, u, shift, fn, W);
         return;
     }
     uint32_t x = 0;
@@ -202,7 +203,7 @@ inline void apm_enum_unit_windows(const uint8_t *pat, const ApmUnit &u, int shif
     for (int i = 0; i < n; ++i) c[i] = (uint8_t)((pat[u.poff + i] >> shift) & 3);
     /* emit the words whose visible part is w[0..ext) with `wild` = bitmask of positions that may hold any code */
     auto emit = [&](const uint8_t *w, uint32_t wild) {
-        int wp[8], nw = 0;
+        int wp[9], nw = 0;
         uint32_t base = 0;
         for (int j = 0; j < ext; ++j) {
             if ((wild >> j) & 1u) wp[nw++] = j;
@@ -214,7 +215,7 @@ inline void apm_enum_unit_windows(const uint8_t *pat, const ApmUnit &u, int shif
             fn(x | (v << (2 * vis)));
         }
     };
-    uint8_t w[8];
+    uint8_t w[9];
     /* no edit inside the visible part / a substitution at i (any code there) */
     for (int i = -1; i < ext && i < n; ++i) {
         uint32_t wild = 0;

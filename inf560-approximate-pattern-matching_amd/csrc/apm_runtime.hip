@@ -405,8 +405,7 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
     }
     S.bitmap.assign(8192, 0u);
     std::vector<uint8_t> seen16(8192, 0); // union of the launches' 16-bit code words (byte x & 8191, bit x >> 13)
-    std::vector<uint8_t> free16(8192, 0); // ... of those whose ninth byte is free for some key (exact part shorter than 9 bytes)
-    std::vector<uint32_t> exact18;        // 18-bit words of keys with >= 9 exact bytes (the window at the key's own position)
+    std::vector<uint32_t> even18(8192, 0); // union of the units' 18-bit words over nine bytes (dword x & 8191, bit x >> 13)
     // nomination units of a pattern (apm_core.h, ApmUnit): per pair of pigeonhole pieces (A, B) either the two
     // piece units "A intact + B within one edit behind it" and "B intact + A within one edit in front of it", or --
     // when both pieces are short -- ONE pair unit "A+B within one edit"; whichever shows fewer 8-byte code words to
@@ -480,6 +479,9 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             } else {
                 apm_enum_unit_windows(V.bytes.data() + dd.byte_off, u, S.code_shift,
                                       [&](uint32_t xx) { wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | (uint64_t)kid); });
+                // the sieve looks at NINE bytes where the key window starts at an even position: the unit's 18-bit words
+                // (a ninth exact byte, or what one edit leaves of the partner there)
+                apm_enum_unit_windows(V.bytes.data() + dd.byte_off, u, S.code_shift, [&](uint32_t x18) { even18[x18 & 8191u] |= 1u << (x18 >> 13); }, 9);
             }
             // packed pre-check record: byte offset of the exact part in the pattern pool | its length << 16 |
             // partner length << 24 (31 = beyond 16) | side << 29
@@ -496,15 +498,6 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             const uint32_t xx = (uint32_t)(wk[i] >> 16) & 0xffffu;
             bmp16[xx & 2047u] |= 1u << (xx >> 11);
             seen16[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
-            if (stride == 1) {
-                for (size_t q = i; q < j; ++q) { // the sieve looks at nine bytes: a key with nine exact bytes fixes the ninth code too
-                    const size_t kid = (size_t)(wk[q] & 0x7fffu);
-                    const ApmUnit &u = units[kid];
-                    const ApmPatDesc &dd = V.descs[V.kinfo[kid] & 0xfffu];
-                    if (u.len >= 9) exact18.push_back(xx | ((uint32_t)((V.bytes[dd.byte_off + (uint32_t)u.off + 8u] >> S.code_shift) & 3) << 16));
-                    else free16[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
-                }
-            }
             if (j - i == 1) {
                 r2s.push_back((uint16_t)(0x8000u | (wk[i] & 0x7fffu)));
             } else {
@@ -540,9 +533,9 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
         S.m_max = std::max(S.m_max, V.m_max);
         S.launches.push_back(std::move(V));
     }
-    // the sieve's bitmap.  Stride 1: over 9-byte windows at EVEN positions -- a key window (16-bit word x) may start at
-    // the even position (then the ninth byte is free, unless the key's exact part is nine bytes or longer) or at the odd
-    // one behind it (then the first byte is free).
+    // the sieve's bitmap.  Stride 1: over 9-byte windows at EVEN positions -- a key window may start at the even position
+    // (the unit's own nine-byte words, apm_enum_unit_windows with W = 9) or at the odd one behind it (its 16-bit word x,
+    // the first byte free).
     // Stride 8: the 16-bit words themselves (dword x & 2047, bit x >> 11).
     long pop16 = 0, pop18 = 0;
     for (uint32_t x = 0; x < 65536u; ++x) {
@@ -552,22 +545,15 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             S.bitmap[x & 2047u] |= 1u << (x >> 11);
             continue;
         }
-        const bool free9 = (free16[x & 8191u] >> (x >> 13)) & 1u;
-        auto set18 = [&](uint32_t c18) {
-            uint32_t &w = S.bitmap[c18 & 8191u];
-            pop18 += !((w >> (c18 >> 13)) & 1u);
-            w |= 1u << (c18 >> 13);
-        };
-        for (uint32_t f = 0; f < 4; ++f) {
-            set18((x << 2) | f);              // the key window starts at the odd position: the first byte is free
-            if (free9) set18(x | (f << 16));  // ... at the even one: the ninth byte is free unless every key of x fixes it (below)
+        for (uint32_t f = 0; f < 4; ++f) { // the key window starts at the odd position behind the lookup: the first byte is free
+            const uint32_t c18 = (x << 2) | f;
+            S.bitmap[c18 & 8191u] |= 1u << (c18 >> 13);
         }
     }
     if (stride == 1)
-        for (const uint32_t c18 : exact18) {
-            uint32_t &w = S.bitmap[c18 & 8191u];
-            pop18 += !((w >> (c18 >> 13)) & 1u);
-            w |= 1u << (c18 >> 13);
+        for (uint32_t i = 0; i < 8192u; ++i) { // ... at the lookup's own position: the units' nine-byte words
+            S.bitmap[i] |= even18[i];
+            pop18 += __builtin_popcount(S.bitmap[i]);
         }
     if (pop16 > 6553) return APM_OK;
     S.rate = stride == 8 ? (double)pop16 / 65536.0 : (double)pop18 / 262144.0;

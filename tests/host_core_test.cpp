@@ -116,8 +116,8 @@ int main() {
             for (int j = i; j < n && ok; ++j) ok = tb[j + 1] == pb[j];
             return ok;
         };
-        long words_def = 0, words_gen = 0, positives = 0;
-        std::vector<unsigned char> in_def(65536), in_gen(65536);
+        long words_def = 0, words_gen = 0, positives = 0, words_def9 = 0, words_gen9 = 0;
+        std::vector<unsigned char> in_def(65536), in_gen(65536), in_def9(262144), in_gen9(262144); // W = 8 / W = 9 (the sieve's even alignment)
         for (int it = 0; it < 3000; it++) {
             const char *alphabet = (it % 3 == 0) ? "ACGT" : ((it % 3 == 1) ? "ACGTN\n" : "abcdefgh");
             const int na = (int)strlen(alphabet);
@@ -135,6 +135,16 @@ int main() {
             std::fill(in_gen.begin(), in_gen.end(), 0);
             apm_enum_unit_windows_bruteforce(pat, u, shift, [&](uint32_t x) { in_def[x & 0xffffu] = 1; });
             apm_enum_unit_windows(pat, u, shift, [&](uint32_t x) { in_gen[x & 0xffffu] = 1; });
+            std::fill(in_def9.begin(), in_def9.end(), 0);
+            std::fill(in_gen9.begin(), in_gen9.end(), 0);
+            apm_enum_unit_windows_bruteforce(pat, u, shift, [&](uint32_t x) { in_def9[x & 0x3ffffu] = 1; }, 9);
+            apm_enum_unit_windows(pat, u, shift, [&](uint32_t x) { in_gen9[x & 0x3ffffu] = 1; }, 9);
+            for (int x = 0; x < 262144; x++) {
+                words_def9 += in_def9[x];
+                words_gen9 += in_gen9[x];
+                if (in_def9[x] && !in_gen9[x]) { bad++; if (bad < 5) printf("enum (W=9) misses word %x (len %d plen %d side %d)\n", x, u.len, u.plen, u.side); break; }
+                if (in_gen9[x] && !in_gen[x & 0xffff]) { bad++; if (bad < 5) printf("a nine-byte word whose first eight bytes are no eight-byte word: %x\n", x); break; }
+            }
             long nd = 0, ng = 0;
             for (int x = 0; x < 65536; x++) {
                 nd += in_def[x];
@@ -163,9 +173,12 @@ int main() {
                 uint32_t x = 0;
                 for (int z = 0; z < 8; z++) x |= (uint32_t)((text[s + z] >> shift) & 3) << (2 * z);
                 positives++;
+                uint32_t x9 = x | ((uint32_t)((text[s + 8] >> shift) & 3) << 16);
+                if (!in_gen9[x9]) { bad++; if (bad < 5) printf("nine-byte window of a true unit occurrence not enumerated (len %d plen %d side %d)\n", u.len, u.plen, u.side); }
                 if (!in_gen[x]) { bad++; if (bad < 5) printf("window of a true unit occurrence not enumerated (len %d plen %d side %d)\n", u.len, u.plen, u.side); }
             }
         }
+        if (words_gen9 > words_def9 * 3 / 2 + 4000) { printf("constructive enumeration (W=9) too loose: %ld vs %ld\n", words_gen9, words_def9); bad++; }
         if (words_gen > words_def * 3 / 2 + 1000) { printf("constructive enumeration too loose: %ld vs %ld\n", words_gen, words_def); bad++; }
         if (positives < 50000) { printf("unit window test saw too few positives\n"); bad++; }
     }
