@@ -43,7 +43,7 @@ def test_product_library_has_no_measurement_switches():
     """Stage-skipping and sizing knobs exist only under -DAPM_MEASURE (make measure -> libapm_hip_measure.so):
     the shipped library must not even contain their names, so no environment variable can change its results."""
     blob = open(H.pkg().LIB_PATH, "rb").read()
-    for name in (b"APM_FILTER_ABLATE", b"APM_MEASURE_SKIP", b"APM_MAX_KEYS", b"APM_BPC_CAP", b"APM_QCAP_S1"):
+    for name in (b"APM_FILTER_ABLATE", b"APM_MEASURE_SKIP", b"APM_MAX_KEYS", b"APM_BPC_CAP", b"APM_QCAP_S1", b"APM_FUSED_THREADS", b"APM_VERIFY_GRID_PCT"):
         assert name not in blob, name
     for sub in ("csrc/apm_kernels.hip", "csrc/apm_runtime.hip", "csrc/apm_sieve.hip"):
         p = os.path.join(H.PKG_DIR, sub)
