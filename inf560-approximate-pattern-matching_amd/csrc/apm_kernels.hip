@@ -18,6 +18,7 @@
  */
 #include "apm_internal.h"
 #include "apm_core.h"
+#include <type_traits>
 #include "apm_device.h"
 
 // ---------------------------------------------------------------------------
@@ -38,6 +39,12 @@ __device__ __forceinline__ uint4 apm_load16_guarded(const uint8_t *text, int64_t
 // lane l receives lane (l-1)'s value; lane 0 keeps `self` (DPP wave_shr:1, 1 VALU op)
 __device__ __forceinline__ int apm_shift_up1(int v) {
     return __builtin_amdgcn_update_dpp(v, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
+// the same with lane 0 receiving zero: one v_mov_b32_dpp without the copy that keeps `self` (lane 0 is a row-0 lane of
+// the wavefront kernel: it never uses what it receives)
+__device__ __forceinline__ int apm_shift_up1z(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -227,12 +234,21 @@ __device__ __forceinline__ uint32_t wf_scan(const uint8_t *s_tile, const uint8_t
         for (int i = 0; i < R; ++i) cp[i] = (uint32_t)(r0 + i + 2) * ONE2; // cell(0, r0+i+1) + 1
         uint32_t upprev = (uint32_t)(r0 + 1) * ONE2;                        // cell(0, r0) + 1
         const int cidx = joff - y0;
+        // text: the lane keeps the two aligned dwords its column lies in and takes the bytes of windows A and B out of
+        // them with ONE v_perm_b32 per step (selector bytes: column & 3 | 0x0c = zero); one aligned ds_read_b32 every
+        // four steps, four steps ahead of its use -- no byte reads, no address arithmetic and no LDS wait in the step.
+        // (columns in front of the tile occur on masked ramp-up steps only: their dwords are read from offset 0)
+        const int cal = cidx & ~3;
+        const uint32_t a0 = (uint32_t)(cidx - cal);
+        const uint32_t sel0 = 0x0c000c00u | a0 | ((a0 + 1u) << 16); // step i of a block: + i * 0x00010001 (a0 + i + 1 <= 7)
+        auto ld = [&](int addr) __attribute__((always_inline)) { return *reinterpret_cast<const uint32_t *>(s_tile + (addr < 0 ? 0 : addr)); };
+        uint32_t lo, hi = ld(cal), nx = ld(cal + 4); // (nx: the dword of the NEXT block, on its way while this one is worked on)
+        int nxt = cal + 8;
 
-        auto step = [&](int s, uint32_t recv) __attribute__((always_inline)) {
+        auto step = [&](int s, uint32_t recv, uint32_t tch2) __attribute__((always_inline)) {
             uint32_t up = row0 ? xbase2 + (uint32_t)s * ONE2 : recv; // cell(x, r0) + 1
             uint32_t dg = upprev;                                    // cell(x-1, r0) + 1
             upprev = up;
-            const uint32_t tch2 = (uint32_t)s_tile[cidx + s] | ((uint32_t)s_tile[cidx + s + 1] << 16);
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const uint32_t left = cp[i];
@@ -244,16 +260,32 @@ __device__ __forceinline__ uint32_t wf_scan(const uint8_t *s_tile, const uint8_t
                 cp[i] = v;
             }
         };
-
+        // MODE 0: every step of the block is a ramp-up step (lanes join one per step); 2: none is; 1: decided per step,
+        // and the block may end early (the blocks around s = Lm - 1 and s = nsteps)
+        auto block = [&](int s0, auto mode) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(mode)::value;
+            lo = hi;
+            hi = nx;
+            nx = ld(nxt);
+            nxt += 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = s0 + i;
+                if (MODE == 1 && s >= nsteps) break;
+                const uint32_t tch2 = __builtin_amdgcn_perm(hi, lo, sel0 + (uint32_t)i * 0x00010001u);
+                const uint32_t recv = (uint32_t)apm_shift_up1z((int)cp[R - 1]);
+                if (MODE == 0 || (MODE == 1 && s < Lm - 1)) {
+                    if (s >= y0) step(s, recv, tch2);
+                } else {
+                    step(s, recv, tch2);
+                }
+            }
+        };
         int s = 0;
-        for (; s < Lm - 1; ++s) { // ramp-up: lanes join one per step
-            const uint32_t recv = (uint32_t)apm_shift_up1((int)cp[R - 1]);
-            if (s >= y0) step(s, recv);
-        }
-        for (; s < nsteps; ++s) {
-            const uint32_t recv = (uint32_t)apm_shift_up1((int)cp[R - 1]);
-            step(s, recv);
-        }
+        for (; s + 4 <= Lm - 1; s += 4) block(s, std::integral_constant<int, 0>());
+        if (s < Lm - 1) { block(s, std::integral_constant<int, 1>()); s += 4; }
+        for (; s + 4 <= nsteps; s += 4) block(s, std::integral_constant<int, 2>());
+        if (s < nsteps) block(s, std::integral_constant<int, 1>());
 
         uint32_t res = cp[0];
 #pragma unroll
