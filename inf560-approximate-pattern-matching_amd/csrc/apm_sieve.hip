@@ -300,7 +300,7 @@ struct ApmVerifyCore {
         ApmWin tw;
         if (side == 1) { // partner behind the piece: text read forward from the end of the piece
             const uint32_t tp = s + (uint32_t)len;
-            if (len == 0) tw = win; // (a pair of short pieces as one unit: its text starts at s itself)
+            if (len == 0 || APM_SKIP(a, 1024)) tw = win; // (a pair of short pieces as one unit: its text starts at s itself)
             else load_win(tp & ~3u, tw);
             apm_lds_dwords<4>(s_pat, at + len, P);
 #pragma unroll
@@ -310,7 +310,8 @@ struct ApmVerifyCore {
             apm_lds_dwords<4>(s_pat, at - 16, Q);
             if (s >= 20u) {
                 const uint32_t tp = s - 20u;
-                load_win(tp & ~3u, tw);
+                if (APM_SKIP(a, 1024)) tw = win; // (measurement: what the dependent gather costs)
+                else load_win(tp & ~3u, tw);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) Wd[i] = __builtin_amdgcn_alignbyte(tw.w[i + 1], tw.w[i], tp & 3u);
             } else { // the first 20 positions of the shard: bytes in front of text[0] do not exist and read as zero

@@ -1,7 +1,12 @@
 """Measurement aid (GPU box): time the bench workload's scan kernel with stages skipped and a
 plain read of the same buffer.  Uses the MEASUREMENT build of the library (make measure ->
 libapm_hip_measure.so, -DAPM_MEASURE): the product library has no such switches.
-Not part of the product or the test-suite."""
+Not part of the product or the test-suite.
+ABLATIONS=a,b,.. = values of APM_MEASURE_SKIP to run (bits, sieve + verify pipeline): 1 the sieve reports no hits,
+8 no nomination predicate (mask walk and window loads only), 16 the predicate runs but nothing survives, 32 no dedup
+test, 64 no DP result, 256 collect the counters of tools/verify_stats.py (atomics: distorts the timing), 512 per-wave
+time stamps, 1024 the predicate takes its partner text out of the window in hand (what the dependent gather costs:
+cfg3 2 %, cfg5 20 % of the verify launch).  APM_VERIFY_GRID_PCT=p launches p % of the verify workgroups."""
 import importlib, os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
