@@ -22,23 +22,21 @@
 #include "apm_device.h"
 #include "apm_sieve.h"
 
+/* tuning constants (each measured on MI355X with tools/ab_libs.sh, one box per comparison) */
 #ifndef APM_WORK_CH
-#define APM_WORK_CH 2u /* blocks per chunk of the dynamic distribution (per-position sets) */
+#define APM_WORK_CH 2u /* blocks per chunk of the dynamic distribution, per-position sets (1, 2, 4: the same within 1 %) */
 #endif
 #ifndef APM_WORK_CH8
-#define APM_WORK_CH8 8u /* ... sampled sets */
+#define APM_WORK_CH8 8u /* ... sampled sets (8, 16: the same) */
 #endif
 #ifndef APM_FUSED_NBLK
-#define APM_FUSED_NBLK 2u /* fused sampled form: blocks per sieve step (1, 2 or 4) */
-#endif
-#ifndef APM_WORK_HASH
-#define APM_WORK_HASH 1
-#endif
-#ifndef APM_FUSED_PIPE
-#define APM_FUSED_PIPE 1 /* the same for the fused form */
+#define APM_FUSED_NBLK 2u /* fused sampled form: blocks per sieve step (2 beats 1 by 4 %, 4 spills) */
 #endif
 #ifndef APM_VERIFY_PIPE
-#define APM_VERIFY_PIPE 2 /* batches formed ahead of the one in hand (measured: 2 beats 1 by 17 % on cfg3: the window loads of batch b+1 then do not wait for the queue reads that form it) */
+#define APM_VERIFY_PIPE 2 /* batches formed ahead of the one in hand (2 beats 1 by 17 % on cfg3: the window loads of batch b+1 then do not wait for the queue reads that form it) */
+#endif
+#ifndef APM_FUSED_PIPE
+#define APM_FUSED_PIPE 1 /* the same for the fused form (1 and 2 equal for sampled sets; 2 costs registers) */
 #endif
 
 typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
@@ -472,7 +470,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     const uint32_t NC = (NB + CH - 1u) / CH;
     // NG = min(APM_WORK_GROUPS, waves of the launch): no group without a wave.  Workgroups go round the XCDs, so the low
     // bits of the wave number alone would tie a group to one XCD and one wave slot: fold the higher bits in
-    const uint32_t NG = (uint32_t)a.work_groups, grp = (APM_WORK_HASH ? (my_wave ^ (my_wave >> 5)) : my_wave) % NG;
+    const uint32_t NG = (uint32_t)a.work_groups, grp = (my_wave ^ (my_wave >> 5)) % NG;
     const uint32_t f_g = (uint32_t)(((uint64_t)NC * grp) / NG), n_g = (uint32_t)(((uint64_t)NC * (grp + 1u)) / NG) - f_g;
     uint32_t *const ctr = a.work + ((uint32_t)a.work_epoch & 1u) * (APM_WORK_GROUPS * APM_WORK_STRIDE) + grp * APM_WORK_STRIDE;
     if (blockIdx.x == 0 && tid < APM_WORK_GROUPS) a.work[(((uint32_t)a.work_epoch + 1u) & 1u) * (APM_WORK_GROUPS * APM_WORK_STRIDE) + (uint32_t)tid * APM_WORK_STRIDE] = 0u;
