@@ -862,6 +862,7 @@ hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, 
 #ifdef APM_MEASURE
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.v.skip_mask = atoi(e);
 #endif
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); // (per device: the geometry query ran on one)
     args.v.work_groups = (int)std::min<int64_t>(APM_WORK_GROUPS, nb * (threads / 64));
     args.v.work_epoch = (*work_epoch)++;
     void *kargs[] = {&args};

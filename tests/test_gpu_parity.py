@@ -896,6 +896,43 @@ def test_window_nominated_only_by_a_shifted_piece_at_tile_start(ctx, apm, m):
     ctx.set_kernel("auto")
 
 
+@pytest.mark.parametrize("P,m,k", [(490, 50, 5), (800, 30, 3)])
+def test_large_pattern_sets_vs_full_dp(apm, P, m, k):
+    """Hundreds of patterns: the verify launch's LDS image passes 64 KiB with its wave buffers (490 x 50, k = 5: 55 KB of
+    image, 512-thread workgroups), or the key set is too dense for the sieve and the tile kernels do the work
+    (800 x 30, k = 3).  AUTO == forced full-DP BITPAR on 8 MiB of random DNA with planted occurrences."""
+    import torch
+    rnd = random.Random(1000 * P + m)
+    n = 8 << 20
+    g = torch.Generator().manual_seed(P)
+    host = torch.tensor(list(b"ACGT"), dtype=torch.uint8)[torch.randint(0, 4, (n,), generator=g)]
+    tb = host.numpy().tobytes()
+    pats = []
+    for _ in range(P):
+        o = rnd.randrange(0, n - m)
+        p = bytearray(tb[o:o + m])
+        for _e in range(rnd.randrange(0, k)):
+            p[rnd.randrange(m)] = rnd.choice(b"ACGT")
+        pats.append(bytes(p))
+    text = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
+    text[:n] = host.to("cuda:0")
+    cnt = torch.zeros(P, dtype=torch.int64, device="cuda:0")
+    with apm.ApmContext(device=0) as c2:
+        c2.set_patterns(pats, k)
+        got = {}
+        for variant in ("auto", "bitpar"):
+            c2.set_kernel(variant)
+            cnt.zero_()
+            torch.cuda.synchronize()
+            c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())
+            c2.synchronize()
+            got[variant] = cnt.cpu().tolist()
+            if variant == "auto" and P == 490:
+                assert c2.stat("sieve_on") == 1 and c2.stat("verify_image_bytes") > 50000
+        assert got["auto"] == got["bitpar"]
+        assert sum(got["auto"]) >= P
+
+
 @pytest.mark.parametrize("seed", [301, 302, 303, 304, 305, 306])
 def test_sieve_pipeline_vs_full_dp_at_scale(apm, seed):
     """Random pattern sets (lengths 12..128 mixed, k = 2..5, patterns cut from the text and edited) on 48 MiB of device
