@@ -91,6 +91,11 @@ struct TiledLaunch {       // host description of one tiled scan launch
     int m_max = 0, m_min = 0, tile = 0;
 };
 
+/* Largest LDS image of a verify launch (bytes): one 512-thread workgroup with its wave buffers still fits a CU.  There is
+ * no density limit on the key set any more: measured on 64 MiB of DNA (tools/density_probe.py) the pipeline beats the tile
+ * kernels by 3.6x at 19 % of all code words set (800 patterns of 30, k = 3), by 90x at 48 % (200 x 16, k = 3). */
+#define APM_VERIFY_IMAGE_MAX (112 * 1024)
+
 struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns and its LDS image (apm_sieve.hip)
     std::vector<ApmPatDesc> descs;    // m, index, byte_off (into bytes), aux_off = first key, w = number of keys
     std::vector<uint8_t> bytes;       // raw pattern bytes
@@ -381,8 +386,9 @@ void mark_key_windows(std::vector<uint8_t> &bmp, const TiledLaunch &L, const Apm
                      [&](uint32_t xx) { bmp[xx & 8191u] |= (uint8_t)(1u << (xx >> 13)); });
 }
 
-// Plan of the sieve + verify pipeline for all BANDED patterns of the set (see build_plan).  Leaves ctx->sieve.on
-// false when the key set is too dense or does not fit the pipeline's limits.
+// Plan of the sieve + verify pipeline for all BANDED patterns of the set (see build_plan): one sieve bitmap for the set,
+// the patterns split into verify launches by LDS image size.  Leaves ctx->sieve.on false only when a launch does not fit
+// the index formats (the splitting keeps clear of that).
 int build_sieve_plan(apm_ctx *ctx, int stride) {
     SievePlan &S = ctx->sieve;
     S.stride = stride;
@@ -437,17 +443,24 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
     for (size_t pos = 0; pos < idx.size();) {
         VerifyLaunch V;
         std::vector<ApmUnit> units; // per key, offsets relative to the pattern
+        size_t n_words = 0;         // code words of the launch's units, counted per pattern (>= the distinct ones)
         for (; pos < idx.size(); ++pos) {
             const PatternInfo &pi = ctx->pats[idx[pos]];
-            if (!V.descs.empty() && (V.bytes.size() + (size_t)pi.m > 24576 || V.kinfo.size() + (size_t)pieces > (stride == 8 ? 2048u : 8192u) || V.descs.size() >= 4096))
+            const std::vector<ApmUnit> us = units_of(reinterpret_cast<const uint8_t *>(pi.bytes.data()), pi.m);
+            const size_t pw = stride == 8 ? us.size() * 8 : count_words(reinterpret_cast<const uint8_t *>(pi.bytes.data()), us);
+            // the image must fit a CU's LDS beside the wave buffers of one workgroup, and the slot indices 15 bits:
+            // bitmap + prefix (12 KiB), rank -> key and key lists (<= 2 + 2 bytes per word), key records, pattern bytes
+            const size_t est = 12288 + 4 * (n_words + pw) + 4 * (V.kinfo.size() + us.size()) + V.bytes.size() + (size_t)pi.m + 512;
+            if (!V.descs.empty() && (V.bytes.size() + (size_t)pi.m > 24576 || V.kinfo.size() + us.size() > (stride == 8 ? 2048u : 8192u) || V.descs.size() >= 4096 ||
+                                     est > APM_VERIFY_IMAGE_MAX || n_words + pw >= 0x7000))
                 break;
+            n_words += pw;
             ApmPatDesc d{};
             d.m = (uint32_t)pi.m;
             d.index = (uint32_t)idx[pos];
             d.byte_off = (uint32_t)V.bytes.size();
             d.aux_off = (uint32_t)V.kinfo.size(); // first key
             V.bytes.insert(V.bytes.end(), pi.bytes.begin(), pi.bytes.end());
-            const std::vector<ApmUnit> us = units_of(reinterpret_cast<const uint8_t *>(pi.bytes.data()), pi.m);
             d.w = (uint32_t)us.size();
             for (size_t ui = 0; ui < us.size(); ++ui) {
                 V.kinfo.push_back((uint32_t)V.descs.size() | ((uint32_t)us[ui].off << 12) | ((uint32_t)ui << 21));
@@ -506,7 +519,7 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             }
             i = j;
         }
-        if (r2s.size() > 6553 || slots.size() >= 0x8000) return APM_OK; // too dense for a list-driven pass: tile kernels
+        if (slots.size() >= 0x8000 || V.kinfo.size() > 0x7fffu) return APM_OK; // (15-bit slot / key indices; the splitting above keeps clear of it)
         uint32_t run = 0;
         for (int w = 0; w < 2048; ++w) {
             prefix[w] = (uint16_t)run;
@@ -555,7 +568,6 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             S.bitmap[i] |= even18[i];
             pop18 += __builtin_popcount(S.bitmap[i]);
         }
-    if (pop16 > 6553) return APM_OK;
     S.rate = stride == 8 ? (double)pop16 / 65536.0 : (double)pop18 / 262144.0;
     S.on = !S.launches.empty();
     return APM_OK;

@@ -896,11 +896,12 @@ def test_window_nominated_only_by_a_shifted_piece_at_tile_start(ctx, apm, m):
     ctx.set_kernel("auto")
 
 
-@pytest.mark.parametrize("P,m,k", [(490, 50, 5), (800, 30, 3)])
+@pytest.mark.parametrize("P,m,k", [(490, 50, 5), (800, 30, 3), (200, 16, 3), (600, 20, 3)])
 def test_large_pattern_sets_vs_full_dp(apm, P, m, k):
     """Hundreds of patterns: the verify launch's LDS image passes 64 KiB with its wave buffers (490 x 50, k = 5: 55 KB of
-    image, 512-thread workgroups), or the key set is too dense for the sieve and the tile kernels do the work
-    (800 x 30, k = 3).  AUTO == forced full-DP BITPAR on 8 MiB of random DNA with planted occurrences."""
+    image, 512-thread workgroups); dense key sets -- a fifth (800 x 30, k = 3), half (200 x 16) and two thirds (600 x 20:
+    several verify launches) of all 16-bit code words set -- stay on the sieve pipeline (no density limit).
+    AUTO == forced full-DP BITPAR on 8 MiB of random DNA with planted occurrences."""
     import torch
     rnd = random.Random(1000 * P + m)
     n = 8 << 20
@@ -927,8 +928,12 @@ def test_large_pattern_sets_vs_full_dp(apm, P, m, k):
             c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())
             c2.synchronize()
             got[variant] = cnt.cpu().tolist()
-            if variant == "auto" and P == 490:
-                assert c2.stat("sieve_on") == 1 and c2.stat("verify_image_bytes") > 50000
+            if variant == "auto":
+                assert c2.stat("sieve_on") == 1 and c2.stat("sieve_stride") == 1
+                if P == 490:
+                    assert c2.stat("verify_image_bytes") > 50000
+                if P == 600:
+                    assert c2.stat("verify_launches") >= 2 and c2.stat("sieve_rate") > 0.5
         assert got["auto"] == got["bitpar"]
         assert sum(got["auto"]) >= P
 
