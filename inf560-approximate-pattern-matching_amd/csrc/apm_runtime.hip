@@ -695,23 +695,35 @@ int build_plan(apm_ctx *ctx) {
     // (pieces shorter than 15 bytes), ONE sieve pass serves all BANDED patterns of the set -- those with longer
     // pieces join with one key per piece instead of a sampled family -- and the verify launches work off its
     // candidate list.  The LDS-tile / stream launches of the same patterns are still planned below: they run as
-    // device-guarded fallbacks (candidate list overflow) and for text the sieve cannot take (unaligned, >= 4 GiB).
-    // Too dense a key set (more than a tenth of all 8-byte code words) stays on the tile kernels.
+    // for text the sieve cannot take (unaligned, >= 4 GiB).
     // APM_SIEVE=0 switches the pipeline off (A/B aid). ----
     ctx->sieve = SievePlan();
     {
         static const int sieve_env = getenv("APM_SIEVE") ? atoi(getenv("APM_SIEVE")) : 1;
         bool has_s1 = false, has_banded = false;
+        size_t stream_keys = 0, stream_bytes = 0, n_banded = 0; // what one stream launch would have to hold (limits of the class loop below)
         for (int i = 0; i < P; ++i) {
             if (ctx->pats[i].kernel != APM_KERNEL_BANDED) continue;
             has_banded = true;
-            if (ctx->pats[i].m / (ctx->k + 1) < 15) has_s1 = true;
+            const int piece = ctx->pats[i].m / (ctx->k + 1);
+            if (piece < 15) has_s1 = true;
+            stream_keys += (size_t)(ctx->k + 1) * (piece >= 31 ? 16u : 8u);
+            stream_bytes += (size_t)ctx->pats[i].m;
+            ++n_banded;
         }
-        // sets of long pieces only: the sampled form of the pipeline (one lookup per 8 bytes) when verification is the
-        // heavy part (k >= 2: pair pre-check + banded DP, which stall the stream kernel's loads); with k <= 1 the stream
-        // kernel already sits on the HBM ceiling (cfg2) and a second launch would only add its fixed cost
+        const bool stream_splits = stream_keys > 4096 || stream_bytes > 16384 || n_banded > 1024;
+        // sets of long pieces only: the sampled form of the pipeline (one lookup per 8 bytes, sieve and verification fused
+        // in one launch) when verification is the heavy part (k >= 2: pair pre-check + banded DP, which stall the stream
+        // kernel's loads) or when the set is too big for ONE stream launch (1000 patterns of 32, k = 0: four stream
+        // launches 0.60 ms per 256 MiB, two fused ones 0.23); a small set with k <= 1 stays on the stream kernel, which
+        // sits on the HBM ceiling there (cfg2: 0.046 ms against 0.060) -- tools/sampled_k_probe.py
         const int stride = has_s1 ? 1 : 8;
-        if (sieve_env && has_banded && (has_s1 || ctx->k >= 2)) {
+#ifdef APM_MEASURE
+        static const int sampled_min_k = getenv("APM_SAMPLED_MIN_K") ? atoi(getenv("APM_SAMPLED_MIN_K")) : 2;
+#else
+        constexpr int sampled_min_k = 2;
+#endif
+        if (sieve_env && has_banded && (has_s1 || ctx->k >= sampled_min_k || stream_splits)) {
             const int rc = build_sieve_plan(ctx, stride);
             if (rc) return rc;
         }

@@ -896,11 +896,12 @@ def test_window_nominated_only_by_a_shifted_piece_at_tile_start(ctx, apm, m):
     ctx.set_kernel("auto")
 
 
-@pytest.mark.parametrize("P,m,k", [(490, 50, 5), (800, 30, 3), (200, 16, 3), (600, 20, 3)])
+@pytest.mark.parametrize("P,m,k", [(490, 50, 5), (800, 30, 3), (200, 16, 3), (600, 20, 3), (1000, 32, 0), (700, 64, 1)])
 def test_large_pattern_sets_vs_full_dp(apm, P, m, k):
     """Hundreds of patterns: the verify launch's LDS image passes 64 KiB with its wave buffers (490 x 50, k = 5: 55 KB of
     image, 512-thread workgroups); dense key sets -- a fifth (800 x 30, k = 3), half (200 x 16) and two thirds (600 x 20:
-    several verify launches) of all 16-bit code words set -- stay on the sieve pipeline (no density limit).
+    several verify launches) of all 16-bit code words set -- stay on the sieve pipeline (no density limit); long pieces
+    with k <= 1 leave the stream kernel for the fused sampled pipeline once one stream launch cannot hold the set.
     AUTO == forced full-DP BITPAR on 8 MiB of random DNA with planted occurrences."""
     import torch
     rnd = random.Random(1000 * P + m)
@@ -912,7 +913,7 @@ def test_large_pattern_sets_vs_full_dp(apm, P, m, k):
     for _ in range(P):
         o = rnd.randrange(0, n - m)
         p = bytearray(tb[o:o + m])
-        for _e in range(rnd.randrange(0, k)):
+        for _e in range(rnd.randrange(0, max(k, 1))):
             p[rnd.randrange(m)] = rnd.choice(b"ACGT")
         pats.append(bytes(p))
     text = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0")
@@ -929,7 +930,9 @@ def test_large_pattern_sets_vs_full_dp(apm, P, m, k):
             c2.synchronize()
             got[variant] = cnt.cpu().tolist()
             if variant == "auto":
-                assert c2.stat("sieve_on") == 1 and c2.stat("sieve_stride") == 1
+                assert c2.stat("sieve_on") == 1 and c2.stat("sieve_stride") == (8 if k <= 1 else 1)
+                if k <= 1 and "APM_FUSED" not in os.environ:
+                    assert c2.stat("sieve_fused") == 1
                 if P == 490:
                     assert c2.stat("verify_image_bytes") > 50000
                 if P == 600:
