@@ -60,7 +60,8 @@ typedef enum apm_status {
  *   WAVEFRONT  full m x m DP, lanes own pattern rows, anti-diagonal sweep with
  *              DPP/__shfl column passing (the kernel BASELINE.json names)
  *   BITPAR     full m x m DP, one window per lane, Myers/Hyyro bit-vector
- *              columns (32 DP cells per integer op), exact distance
+ *              columns (32 DP cells per integer op, up to 16 words: m <= 512),
+ *              exact distance
  *   BANDED     exact for the predicate dist<=k: only diagonals |x-y|<=k/2,
  *              early exit, candidates pre-filtered by pigeonhole sub-keys looked up
  *              in an LDS hash table (needs m<=256, k<=7, m/(k+1)>=4)

@@ -10,7 +10,7 @@
 
 #define APM_BLOCK 256          /* threads per workgroup: 4 wave64 */
 #define APM_TILE_SLACK 320     /* bytes readable past tile+halo in LDS (ramp-down reads, 16B rounding) */
-#define APM_BITPAR_MAX_M 128
+#define APM_BITPAR_MAX_M 512
 #define APM_WAVEFRONT_MAX_M 256
 #define APM_LDS_TABLE_BUDGET (40 * 1024)
 #define APM_BANDED_MAX_M 256
@@ -150,6 +150,7 @@ struct ApmFilterArgs {
 /* launchers (apm_kernels.hip) */
 hipError_t apm_launch_filter(const ApmFilterArgs &a, int max_blocks, hipStream_t s);
 hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s);
+hipError_t apm_launch_tail_wide(const ApmTailArgs &a, int n_pats, hipStream_t s); /* 128 < m <= 512 */
 size_t apm_filter_lds_bytes(const ApmFilterArgs &a);
 int apm_filter_blocks_per_cu(int band, int key_len, int stride, int dma, size_t lds);
 hipError_t apm_launch_stream(const ApmFilterArgs &a, int max_blocks, hipStream_t s);

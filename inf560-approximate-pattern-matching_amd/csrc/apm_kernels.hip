@@ -61,12 +61,22 @@ __device__ __forceinline__ void bp_load_eq(const uint32_t *tab, uint32_t c, uint
         const uint2 v = reinterpret_cast<const uint2 *>(tab)[c];
         eq[0] = v.x;
         eq[1] = v.y;
-    } else {
+    } else if constexpr (STRIDE == 4) {
         const uint4 v = reinterpret_cast<const uint4 *>(tab)[c];
         eq[0] = v.x;
         eq[1] = v.y;
         eq[2] = v.z;
         if constexpr (W == 4) eq[3] = v.w;
+    } else { // W = STRIDE = 8 or 16 words (patterns of 129 .. 512 bytes)
+        static_assert(W == STRIDE && (STRIDE == 8 || STRIDE == 16), "bit-vector widths beyond 4 words come in 8 and 16");
+#pragma unroll
+        for (int q = 0; q < STRIDE / 4; ++q) {
+            const uint4 v = reinterpret_cast<const uint4 *>(tab)[c * (STRIDE / 4) + q];
+            eq[4 * q] = v.x;
+            eq[4 * q + 1] = v.y;
+            eq[4 * q + 2] = v.z;
+            eq[4 * q + 3] = v.w;
+        }
     }
 }
 
@@ -117,6 +127,9 @@ __device__ __forceinline__ uint32_t bp_scan(const uint8_t *s_tile, const uint32_
     return cnt;
 }
 
+// WIDE: the launch's patterns are all longer than 128 bytes (columns of 8 or 16 words: ~150 VGPRs); their own
+// instantiation, so that the short-column launches keep their occupancy
+template <bool WIDE>
 __global__ __launch_bounds__(APM_BLOCK) void apm_bitpar_kernel(ApmScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -152,11 +165,16 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_bitpar_kernel(ApmScanArgs a) {
         const int64_t je_p = min(a.je, a.nrel - m + 1);
         const uint32_t *tab = s_tab + d.aux_off;
         uint32_t cnt;
-        switch (d.w) {
-        case 1: cnt = bp_scan<1, 1>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
-        case 2: cnt = bp_scan<2, 2>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
-        case 3: cnt = bp_scan<3, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
-        default: cnt = bp_scan<4, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
+        if constexpr (WIDE) {
+            if (d.w == 8) cnt = bp_scan<8, 8>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos);
+            else cnt = bp_scan<16, 16>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos);
+        } else {
+            switch (d.w) {
+            case 1: cnt = bp_scan<1, 1>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
+            case 2: cnt = bp_scan<2, 2>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
+            case 3: cnt = bp_scan<3, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
+            default: cnt = bp_scan<4, 4>(s_tile, tab, m, a.k, base, a.jb, je_p, a.tile, tid, a.pos); break;
+            }
         }
         if (lane == 0 && cnt) atomicAdd(&s_cnt[p], cnt);
     }
@@ -177,7 +195,8 @@ hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s) {
     if (span <= 0 || a.n_pats <= 0) return hipSuccess;
     const int64_t nt = (span + a.tile - 1) / a.tile;
     if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(apm_bitpar_kernel, dim3((unsigned)nt), dim3(APM_BLOCK), apm_bitpar_lds_bytes(a), s, a);
+    if (a.halo >= 128) hipLaunchKernelGGL(apm_bitpar_kernel<true>, dim3((unsigned)nt), dim3(APM_BLOCK), apm_bitpar_lds_bytes(a), s, a); // (the runtime never mixes)
+    else hipLaunchKernelGGL(apm_bitpar_kernel<false>, dim3((unsigned)nt), dim3(APM_BLOCK), apm_bitpar_lds_bytes(a), s, a);
     return hipGetLastError();
 }
 
@@ -445,6 +464,55 @@ __global__ __launch_bounds__(128) void apm_tail_kernel(ApmTailArgs a) {
 hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s) {
     if (n_pats <= 0 || a.je <= a.jb) return hipSuccess;
     hipLaunchKernelGGL(apm_tail_kernel, dim3((unsigned)n_pats), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+// The same for 128 < m <= 512: 16-word columns, up to 511 truncated windows per pattern, one per thread of a 512-thread
+// workgroup; Eq table of 256 x 16 words in LDS.  A launch of its own (its registers would cost the sieve kernels, where
+// the short tails ride, their occupancy); it replaces the one-column GENERIC kernel, whose serial global-memory DP
+// took 8 - 30 ms per call for these few windows.
+__global__ __launch_bounds__(512) void apm_tail_wide_kernel(ApmTailArgs a) {
+    constexpr int W = 16, NT = 32 * W;
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[256 * W];
+    __shared__ uint8_t s_txt[NT + 16]; // the last <= 512 text bytes
+    const int tid = threadIdx.x;
+    const ApmPatDesc d = a.pats[blockIdx.x];
+    const int m = (int)d.m;
+    const uint8_t *pat = a.bytes + d.byte_off;
+    for (int i = tid; i < 256 * W; i += 512) s_eq[i] = 0u;
+    const int64_t first_trunc = max(a.jb, a.nrel - m + 1);
+    const int64_t t0 = a.nrel - NT > 0 ? a.nrel - NT : 0;
+    s_txt[tid] = (t0 + tid < a.nrel) ? a.text[t0 + tid] : (uint8_t)0;
+    __syncthreads();
+    if (tid < m) atomicOr(&s_eq[(int)pat[tid] * W + (tid >> 5)], 1u << (tid & 31));
+    __syncthreads();
+    const int64_t j = first_trunc + tid;
+    const bool valid = j < a.je; // (j < nrel - k <= nrel: at least one byte)
+    const int size = valid ? (int)(a.nrel - j) : 0; // 1 .. m-1
+    const int lo = valid ? (int)(j - t0) : 0;
+    uint32_t pv[W], mv[W];
+    bp_init<W>(pv, mv);
+    for (int x = 0; x < m - 1; ++x) {
+        if (x < size) {
+            uint32_t eq[W];
+            const uint4 *row = reinterpret_cast<const uint4 *>(s_eq + (int)s_txt[lo + x] * W);
+#pragma unroll
+            for (int q = 0; q < W / 4; ++q) {
+                const uint4 v = row[q];
+                eq[4 * q] = v.x; eq[4 * q + 1] = v.y; eq[4 * q + 2] = v.z; eq[4 * q + 3] = v.w;
+            }
+            bp_step<W>(pv, mv, eq);
+        }
+    }
+    const bool hit = valid && bp_distance<W>(pv, mv, size, size) <= a.k;
+    if (a.pos.out && hit) apm_push_pos(a.pos, j);
+    const uint32_t cnt = apm_wave_count(hit);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
+}
+
+hipError_t apm_launch_tail_wide(const ApmTailArgs &a, int n_pats, hipStream_t s) {
+    if (n_pats <= 0 || a.je <= a.jb) return hipSuccess;
+    hipLaunchKernelGGL(apm_tail_wide_kernel, dim3((unsigned)n_pats), dim3(512), 0, s, a);
     return hipGetLastError();
 }
 

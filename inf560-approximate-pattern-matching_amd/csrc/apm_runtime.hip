@@ -148,6 +148,7 @@ struct DeviceState {
     uint8_t *d_allpat = nullptr;              // every pattern's raw bytes, concatenated
     ApmPatDesc *d_tail_descs = nullptr;       // tails of tiled-kernel patterns with m > 128 (generic kernel)
     ApmPatDesc *d_stail_descs = nullptr;      // tails of tiled-kernel patterns with m <= 128 (tail kernel)
+    ApmPatDesc *d_wtail_descs = nullptr;      // ... with 128 < m <= 512 (wide tail kernel)
     ApmPatDesc *d_long_descs = nullptr;       // generic full-scan patterns
     int *d_trivial = nullptr;                 // indices of the patterns with k >= m
     std::vector<DevTiled> tiled;
@@ -202,6 +203,7 @@ struct apm_ctx {
     SievePlan sieve;
     GenericGroup tails;   // tiled-kernel patterns with m > 128: tails by the generic kernel
     GenericGroup stails;  // tiled-kernel patterns with m <= 128: tails by the bit-vector tail kernel
+    GenericGroup wtails;  // ... with 128 < m <= 512: by its 16-word form (tails: beyond 512 only)
     GenericGroup longs;   // patterns scanned fully by the generic kernel
     std::vector<int> trivial; // indices with k >= m
     std::vector<uint8_t> allpat;
@@ -274,9 +276,8 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
     if (forced == APM_KERNEL_AUTO) {
         if (k >= m) return KERNEL_TRIVIAL;
         if (m <= APM_BANDED_MAX_M && k <= APM_BANDED_MAX_K && m / (k + 1) >= APM_BANDED_MIN_PIECE) return APM_KERNEL_BANDED;
-        if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR;
-        if (m <= APM_WAVEFRONT_MAX_M) return APM_KERNEL_WAVEFRONT; // long and loose (BANDED's pigeonhole pieces too short): LDS/DPP sweep
-        return APM_KERNEL_GENERIC;                                 // m > 256 only
+        if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR; // short or loose (BANDED's pigeonhole pieces too short): bit-vector columns of up to 16 words
+        return APM_KERNEL_GENERIC;                           // m > 512 only
     }
     switch (forced) {
     case APM_KERNEL_GENERIC: return APM_KERNEL_GENERIC;
@@ -284,7 +285,7 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
         if (m > APM_WAVEFRONT_MAX_M) { *why = "WAVEFRONT kernel supports pattern length <= 256"; return -100; }
         return APM_KERNEL_WAVEFRONT;
     case APM_KERNEL_BITPAR:
-        if (m > APM_BITPAR_MAX_M) { *why = "BITPAR kernel supports pattern length <= 128"; return -100; }
+        if (m > APM_BITPAR_MAX_M) { *why = "BITPAR kernel supports pattern length <= 512"; return -100; }
         return APM_KERNEL_BITPAR;
     case APM_KERNEL_BANDED:
         if (m > APM_BANDED_MAX_M || k > APM_BANDED_MAX_K || m / (k + 1) < APM_BANDED_MIN_PIECE) {
@@ -309,6 +310,7 @@ void free_device_plan(DeviceState &ds) {
     if (ds.d_allpat) hipFree(ds.d_allpat), ds.d_allpat = nullptr;
     if (ds.d_tail_descs) hipFree(ds.d_tail_descs), ds.d_tail_descs = nullptr;
     if (ds.d_stail_descs) hipFree(ds.d_stail_descs), ds.d_stail_descs = nullptr;
+    if (ds.d_wtail_descs) hipFree(ds.d_wtail_descs), ds.d_wtail_descs = nullptr;
     if (ds.d_long_descs) hipFree(ds.d_long_descs), ds.d_long_descs = nullptr;
     if (ds.d_trivial) hipFree(ds.d_trivial), ds.d_trivial = nullptr;
     if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
@@ -577,6 +579,7 @@ int build_plan(apm_ctx *ctx) {
     ctx->tiled.clear();
     ctx->tails = GenericGroup();
     ctx->stails = GenericGroup();
+    ctx->wtails = GenericGroup();
     ctx->longs = GenericGroup();
     ctx->trivial.clear();
     ctx->allpat.clear();
@@ -597,7 +600,7 @@ int build_plan(apm_ctx *ctx) {
         d.byte_off = raw_off[i];
         d.index = (uint32_t)i;
         if (kv != APM_KERNEL_GENERIC) { // GENERIC scans truncated windows itself (mode 2)
-            GenericGroup &tg = ctx->pats[i].m <= 128 ? ctx->stails : ctx->tails;
+            GenericGroup &tg = ctx->pats[i].m <= 128 ? ctx->stails : (ctx->pats[i].m <= 512 ? ctx->wtails : ctx->tails);
             tg.descs.push_back(d);
             tg.m_max = std::max(tg.m_max, ctx->pats[i].m);
         } else {
@@ -610,10 +613,14 @@ int build_plan(apm_ctx *ctx) {
     {
         std::vector<int> idx;
         for (int i = 0; i < P; ++i) if (ctx->pats[i].kernel == APM_KERNEL_BITPAR) idx.push_back(i);
+        // patterns beyond 128 bytes (8- and 16-word columns) get launches of their own: a separate, register-hungry
+        // instantiation of the kernel (apm_launch_bitpar picks it by the launch's m_max)
+        std::stable_partition(idx.begin(), idx.end(), [&](int i) { return ctx->pats[i].m <= 128; });
         size_t pos = 0;
         while (pos < idx.size()) {
             TiledLaunch L;
             L.kind = APM_KERNEL_BITPAR;
+            const bool wide = ctx->pats[idx[pos]].m > 128;
             L.tile = 1024;
             bool present[256] = {false};
             int n_codes = 1; // code 0 = absent
@@ -621,6 +628,7 @@ int build_plan(apm_ctx *ctx) {
             std::vector<int> members;
             while (pos < idx.size() && members.size() < 1024) {
                 const PatternInfo &pi = ctx->pats[idx[pos]];
+                if ((pi.m > 128) != wide) break;
                 bool p2[256];
                 memcpy(p2, present, sizeof p2);
                 int nc = n_codes;
@@ -628,7 +636,7 @@ int build_plan(apm_ctx *ctx) {
                 const int entries = nc > 256 ? 256 : nc;
                 // every member's table is re-laid with the launch's final code count: bound with `entries`
                 size_t w_total = 0;
-                auto stride_of = [](int m) { const int w = (m + 31) / 32; return w == 3 ? 4 : w; };
+                auto stride_of = [](int m) { const int w = (m + 31) / 32; return w <= 2 ? w : (w <= 4 ? 4 : (w <= 8 ? 8 : 16)); };
                 for (int mi : members) w_total += (size_t)entries * stride_of(ctx->pats[mi].m);
                 w_total += (size_t)entries * stride_of(pi.m);
                 if (!members.empty() && w_total * 4 > APM_LDS_TABLE_BUDGET) break;
@@ -648,7 +656,8 @@ int build_plan(apm_ctx *ctx) {
                 const PatternInfo &pi = ctx->pats[mi];
                 ApmPatDesc d{};
                 d.m = (uint32_t)pi.m;
-                d.w = (uint32_t)((pi.m + 31) / 32);
+                const uint32_t w32 = (uint32_t)((pi.m + 31) / 32);      // words of the bit vector: 1, 2, 3, 4, then 8 and 16
+                d.w = w32 <= 4 ? w32 : (w32 <= 8 ? 8u : 16u);           // (the rows past m never reach the distance)
                 d.stride = d.w == 3 ? 4 : d.w;
                 d.index = (uint32_t)mi;
                 d.byte_off = 0;
@@ -932,6 +941,7 @@ int build_plan(apm_ctx *ctx) {
         if ((rc = upload_vec(ctx, &ds.d_allpat, ctx->allpat))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_tail_descs, ctx->tails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_stail_descs, ctx->stails.descs))) return rc;
+        if ((rc = upload_vec(ctx, &ds.d_wtail_descs, ctx->wtails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_long_descs, ctx->longs.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_trivial, ctx->trivial))) return rc;
         HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
@@ -1349,6 +1359,20 @@ int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t te
     }
     if (tails_pending) {
         HIP_TRY(ctx, apm_launch_tail(ta, (int)ctx->stails.descs.size(), ds.stream));
+        { const int nrc = note_launch(ctx, ds, "tail"); if (nrc) return nrc; }
+    }
+    if (!ctx->wtails.descs.empty() && nrel - (int64_t)ctx->wtails.m_max + 1 < je) { // truncated windows of the 128 < m <= 512 patterns
+        ApmTailArgs tw{};
+        tw.text = d_text;
+        tw.jb = jb;
+        tw.je = je;
+        tw.nrel = nrel;
+        tw.pats = ds.d_wtail_descs;
+        tw.bytes = ds.d_allpat;
+        tw.counts = d_counts;
+        tw.k = ctx->k;
+        tw.pos = sink;
+        HIP_TRY(ctx, apm_launch_tail_wide(tw, (int)ctx->wtails.descs.size(), ds.stream));
         { const int nrc = note_launch(ctx, ds, "tail"); if (nrc) return nrc; }
     }
     if (!ctx->trivial.empty()) {

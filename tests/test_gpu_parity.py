@@ -15,7 +15,7 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 VARIANTS = ["auto", "banded", "bitpar", "wavefront", "generic"]
-MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 128, "wavefront": 256, "banded": 256}
+MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 512, "wavefront": 256, "banded": 256}
 
 
 def _supported(variant, m, k):
@@ -378,18 +378,53 @@ def test_full_size_counts_pinned_by_full_dp_kernel(ctx, apm, cfg):
     del text
 
 
-def test_auto_routes_long_loose_patterns_to_wavefront(ctx, apm):
-    """128 < m <= 256 where BANDED does not apply (k > 7 or pieces shorter than 4 bytes): the LDS/DPP wavefront
-    kernel, not the global-memory GENERIC one; m > 256 stays GENERIC; counts = the reference's (golden)."""
+def test_auto_routes_long_loose_patterns_to_bitpar(ctx, apm):
+    """m <= 512 where BANDED does not apply (k > 7 or pieces shorter than 4 bytes): the bit-vector kernel with columns of
+    up to 16 words, not the global-memory GENERIC one (nor the 14 x slower wavefront kernel, which AUTO no longer picks);
+    m > 512 stays GENERIC; counts = the reference's (golden)."""
     for name in ("chrY_loose_long_k60", "chrY_loose_long_k8", "dna20k_loose_long_k9"):
         c = next(c for c in CASES if c["name"] == name)
         ctx.set_kernel("auto")
         ctx.set_patterns(c["patterns"], c["k"])
         for i, p in enumerate(c["patterns"]):
-            assert ctx.pattern_kernel(i) == (2 if 128 < len(p) <= 256 else 3), (name, len(p))
+            assert ctx.pattern_kernel(i) == 3, (name, len(p))
         assert ctx.count_buffer(H.case_text(c)) == c["counts"]
     ctx.set_patterns([b"A" * 300], 100)
+    assert ctx.pattern_kernel(0) == 3
+    ctx.set_patterns([b"A" * 600], 100)
     assert ctx.pattern_kernel(0) == 1
+
+
+@pytest.mark.parametrize("m,k", [(129, 40), (200, 9), (256, 64), (257, 3), (300, 20), (400, 150), (512, 8)])
+def test_wide_bitvector_columns_vs_oracle(ctx, apm, m, k):
+    """BITPAR with 8- and 16-word columns (129 <= m <= 512): planted occurrences with substitutions and indels in 60 KB of
+    DNA, truncated tail windows included; AUTO and forced BITPAR == the CPU oracle (and == GENERIC)."""
+    rnd = random.Random(7 * m + k)
+    n = 60000
+    text = bytearray(rnd.choice(b"ACGT") for _ in range(n))
+    pat = bytes(rnd.choice(b"ACGT") for _ in range(m))
+    for i in range(12):
+        w = bytearray(pat)
+        for _e in range(rnd.randrange(0, min(k, 12) + 1)):
+            r, pos = rnd.random(), rnd.randrange(len(w))
+            if r < 0.6:
+                w[pos] = rnd.choice(b"ACGT")
+            elif r < 0.8:
+                del w[pos]
+                w.append(rnd.choice(b"ACGT"))
+            else:
+                w.insert(pos, rnd.choice(b"ACGT"))
+                w.pop()
+        o = n - m - 3 if i == 0 else rnd.randrange(0, n - m)     # one right at the end of the text
+        text[o:o + m] = w
+    text = bytes(text)
+    want = H.oracle_counts(text, [pat], k)
+    assert want[0] >= 1
+    for variant in ("auto", "bitpar", "generic"):
+        ctx.set_kernel(variant)
+        ctx.set_patterns([pat], k)
+        assert ctx.count_buffer(text) == want, (variant, m, k)
+    ctx.set_kernel("auto")
 
 
 def test_reference_gpu_entry_points_link_level(tmp_path):
