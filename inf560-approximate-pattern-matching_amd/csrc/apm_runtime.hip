@@ -1022,9 +1022,35 @@ int launch_generic_group(apm_ctx *ctx, DeviceState &ds, const GenericGroup &g, c
     return APM_OK;
 }
 
-// the shard scan proper, all on ds.stream, no host sync
+int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t text_off, uint64_t text_len,
+                   uint64_t n_total, uint64_t own_begin, uint64_t own_end, unsigned long long *d_counts);
+
+// The sieve pipeline addresses its shard with 32 bits.  A bigger shard (a 288 GB device holds a lot of text) is scanned
+// in pieces of 3 GiB of window starts, each with its own text window [piece begin rounded down so that the pointer
+// keeps its 16-byte alignment, piece end + m_max + 31) -- the same cut a caller sharding the text would make (every
+// window lies in exactly one piece; what a piece reads in front of its first window start never decides a match).
 int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t text_off, uint64_t text_len,
                uint64_t n_total, uint64_t own_begin, uint64_t own_end, unsigned long long *d_counts) {
+    const uint64_t lim32 = ((uint64_t)1 << 32) - 4096;
+    if (!ctx->sieve.on || text_len < lim32 || (reinterpret_cast<uintptr_t>(d_text) & 15u) != 0 || own_begin < text_off)
+        return scan_shard_one(ctx, ds, d_text, text_off, text_len, n_total, own_begin, own_end, d_counts);
+    const uint64_t k = (uint64_t)ctx->k;
+    const uint64_t oe = std::min(own_end, n_total > k ? n_total - k : 0);
+    const uint64_t m_max = (uint64_t)std::max(ctx->m_max, 1), step = (uint64_t)3 << 30;
+    for (uint64_t b = own_begin; b < oe;) {
+        const uint64_t e = std::min(oe, b + step);
+        const uint64_t sb = text_off + ((b - text_off) & ~(uint64_t)15);
+        const uint64_t se = std::min(text_off + text_len, e + m_max + 31);
+        const int rc = scan_shard_one(ctx, ds, d_text + (sb - text_off), sb, se - sb, n_total, b, e, d_counts);
+        if (rc) return rc;
+        b = e;
+    }
+    return APM_OK;
+}
+
+// the shard scan proper, all on ds.stream, no host sync
+int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t text_off, uint64_t text_len,
+                   uint64_t n_total, uint64_t own_begin, uint64_t own_end, unsigned long long *d_counts) {
     const uint64_t k = (uint64_t)ctx->k;
     const uint64_t limit = n_total > k ? n_total - k : 0;
     const uint64_t ob = own_begin, oe = std::min(own_end, limit);

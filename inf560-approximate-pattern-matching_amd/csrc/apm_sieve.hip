@@ -15,8 +15,8 @@
  *                       piece compare + pair pre-check against global text (bounds-checked buffer loads), the
  *                       survivors of a wave are collected and the banded DP + stateless dedup run on dense lanes.
  *
- * Both need a 16-byte aligned text pointer and a shard of < 4 GiB; the runtime falls back to the LDS-tile
- * kernels of apm_kernels.hip otherwise.
+ * Both need a 16-byte aligned text pointer and a shard of < 4 GiB: the runtime scans bigger shards in pieces and falls
+ * back to the LDS-tile kernels of apm_kernels.hip for unaligned pointers.
  */
 #include <algorithm>
 #include "apm_device.h"

@@ -561,10 +561,11 @@ def test_text_beyond_4gib_on_device(ctx, apm):
     assert t["text_bytes"] >= n
 
 
-def test_sieve_pipeline_and_tile_kernels_agree_beyond_4gib(apm):
-    """5 GiB of device text with BASELINE cfg3's pattern set: as ONE shard it is beyond the sieve + verify pipeline's
-    32-bit offsets and runs on the LDS-tile / stream kernels; cut into two owner-computes shards (each < 4 GiB) it runs
-    through the pipeline.  Same counts, planted occurrences found (64-bit positions, shard seams, both kernel families)."""
+def test_shard_beyond_4gib_runs_the_pipeline_in_pieces(apm):
+    """5 GiB of device text with BASELINE cfg3's pattern set as ONE shard: beyond the sieve + verify pipeline's 32-bit
+    offsets, so the runtime scans it in pieces of 3 GiB of window starts (a piece seam in the middle of the text).
+    Same counts as the caller's own cut into two shards at another place, and as the full-DP BITPAR kernel on the whole
+    5 GiB (64-bit positions, both seams, two kernel families); planted occurrences found."""
     import torch
     wl = H.workloads()
     c = wl.CONFIGS["cfg3"]
@@ -580,7 +581,8 @@ def test_sieve_pipeline_and_tile_kernels_agree_beyond_4gib(apm):
         c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())
         c2.synchronize()
         whole = cnt.cpu().tolist()
-        assert c2.stat("sieve_fused") == 0 and c2.stat("sieve_candidates") == 0   # the one-shard call did not use the pipeline
+        assert c2.stat("sieve_candidates") > 0                      # the pipeline ran (the last piece's masks)
+        assert [l for l, _ in c2.launch_times()].count("tile") == 0
         cnt.zero_()
         torch.cuda.synchronize()
         cut = (n // 2 + 12345) & ~15
@@ -588,7 +590,12 @@ def test_sieve_pipeline_and_tile_kernels_agree_beyond_4gib(apm):
             end = min(n, hi + m_max - 1)
             c2.count_shard_device(text.data_ptr() + lo, lo, end - lo, n, lo, hi, cnt.data_ptr())
             c2.synchronize()
-            assert c2.stat("sieve_fused") == 1 or c2.stat("sieve_candidates") > 0
+        assert cnt.cpu().tolist() == whole
+        c2.set_kernel("bitpar")
+        cnt.zero_()
+        torch.cuda.synchronize()
+        c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())
+        c2.synchronize()
         assert cnt.cpu().tolist() == whole
     for cc, (o, d) in zip(whole, planted):
         assert cc >= (1 if d <= k else 0)
