@@ -1032,6 +1032,14 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
 int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t text_off, uint64_t text_len,
                uint64_t n_total, uint64_t own_begin, uint64_t own_end, unsigned long long *d_counts) {
     const uint64_t lim32 = ((uint64_t)1 << 32) - 4096;
+    // an unaligned text pointer into a bigger buffer: start the shard's text at the 16-byte boundary in front of it (those
+    // bytes are readable -- apm.h -- and lie in front of every window start of the shard, where nothing decides a match)
+    const uint64_t mis = (uint64_t)(reinterpret_cast<uintptr_t>(d_text) & 15u);
+    if (ctx->sieve.on && mis != 0 && text_off >= mis && text_len > 0) {
+        d_text -= mis;
+        text_off -= mis;
+        text_len += mis;
+    }
     if (!ctx->sieve.on || text_len < lim32 || (reinterpret_cast<uintptr_t>(d_text) & 15u) != 0 || own_begin < text_off)
         return scan_shard_one(ctx, ds, d_text, text_off, text_len, n_total, own_begin, own_end, d_counts);
     const uint64_t k = (uint64_t)ctx->k;
