@@ -471,12 +471,9 @@ hipError_t apm_launch_tail(const ApmTailArgs &a, int n_pats, hipStream_t s) {
 // workgroup; Eq table of 256 x 16 words in LDS.  A launch of its own (its registers would cost the sieve kernels, where
 // the short tails ride, their occupancy); it replaces the one-column GENERIC kernel, whose serial global-memory DP
 // took 8 - 30 ms per call for these few windows.
-__global__ __launch_bounds__(512) void apm_tail_wide_kernel(ApmTailArgs a) {
-    constexpr int W = 16, NT = 32 * W;
-    __shared__ __attribute__((aligned(16))) uint32_t s_eq[256 * W];
-    __shared__ uint8_t s_txt[NT + 16]; // the last <= 512 text bytes
-    const int tid = threadIdx.x;
-    const ApmPatDesc d = a.pats[blockIdx.x];
+template <int W>
+__device__ __forceinline__ void apm_tail_wide_body(const ApmTailArgs &a, const ApmPatDesc &d, uint32_t *s_eq, uint8_t *s_txt, int tid) {
+    constexpr int NT = 512; // text bytes staged (the workgroup's threads)
     const int m = (int)d.m;
     const uint8_t *pat = a.bytes + d.byte_off;
     for (int i = tid; i < 256 * W; i += 512) s_eq[i] = 0u;
@@ -508,6 +505,14 @@ __global__ __launch_bounds__(512) void apm_tail_wide_kernel(ApmTailArgs a) {
     if (a.pos.out && hit) apm_push_pos(a.pos, j);
     const uint32_t cnt = apm_wave_count(hit);
     if ((tid & 63) == 0 && cnt) atomicAdd(&a.counts[d.index], (unsigned long long)cnt);
+}
+
+__global__ __launch_bounds__(512) void apm_tail_wide_kernel(ApmTailArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_eq[256 * 16];
+    __shared__ uint8_t s_txt[512 + 16]; // the last <= 512 text bytes
+    const ApmPatDesc d = a.pats[blockIdx.x];
+    if (d.m <= 256) apm_tail_wide_body<8>(a, d, s_eq, s_txt, (int)threadIdx.x); // (8-word columns: half the work per text byte)
+    else apm_tail_wide_body<16>(a, d, s_eq, s_txt, (int)threadIdx.x);
 }
 
 hipError_t apm_launch_tail_wide(const ApmTailArgs &a, int n_pats, hipStream_t s) {
