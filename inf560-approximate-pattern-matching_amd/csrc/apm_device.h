@@ -204,4 +204,16 @@ __device__ __forceinline__ void apm_tail_body(const ApmTailArgs &a, int pat_slot
 }
 
 
+// 16 text bytes at pos, zeros outside [0, avail)
+__device__ __forceinline__ uint4 apm_load16_guarded(const uint8_t *text, int64_t pos, int64_t avail) {
+    if (pos >= 0 && pos + 16 <= avail) return *reinterpret_cast<const uint4 *>(text + pos);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const int64_t q = pos + b;
+        if (q >= 0 && q < avail) w[b >> 2] |= (uint32_t)text[q] << (8 * (b & 3));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 #endif /* APM_DEVICE_H */
