@@ -748,7 +748,8 @@ def _oracle_positions(text, p, k):
 def test_find_positions_equal_oracle(ctx, apm):
     rnd = random.Random(31)
     text = bytes(rnd.choice(b"ACGT") for _ in range(3000)) + b"ACGTACGTAC"
-    pats = [text[100:132], text[500:516], b"ACGTACGTACGT", text[1000:1200], b"GG"]
+    pats = [text[100:132], text[500:516], b"ACGTACGTACGT", text[1000:1200], b"GG",
+            text[2600:2900], text[-260:] + b"TTTTTT", text[2000:2512]]   # 16-word columns; a truncated tail window of a long pattern
     for k in (0, 2, 3):
         ctx.set_kernel("auto")
         ctx.set_patterns(pats, k)
