@@ -137,6 +137,57 @@ APM_HD bool apm_ext1_core16(const uint32_t (&p)[4], const uint32_t (&t)[5], int 
 }
 
 /* ---------------------------------------------------------------------------
+ * The same one-edit extension on strings of 2-bit CODES (code i in bits 2i..2i+1), n <= 15 codes of the partner
+ * against 16 codes of text: the sieve's second stage (apm_sieve.hip, "code filter") runs it on the codes it has
+ * in hand.  Equal bytes have equal codes, so every byte-level alignment with <= 1 edit is one of the code
+ * strings too, and a prefix of such an alignment has <= 1 edit: the result is a superset of what
+ * apm_ext1_core16 accepts for the whole partner -- a filter, never a decision.
+ * ------------------------------------------------------------------------- */
+APM_HD bool apm_ext1_codes(uint32_t p, uint32_t t, int n) {
+    const uint32_t maskn = (1u << (2 * n)) - 1u;
+    const uint32_t x0 = (p ^ t) & maskn;
+    if (x0 == 0u) return true;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int i2 = (__ffs((int)x0) - 1) & ~1; /* bit index of the first mismatching code */
+#else
+    const int i2 = __builtin_ctz(x0) & ~1;
+#endif
+    if (i2 >= 2 * (n - 1)) return true;
+    const uint32_t g = 0xffffffffu << (i2 + 2), e = 0xffffffffu << i2;
+    if ((x0 & g) == 0u) return true;                          /* substitution at i */
+    if (((p ^ (t << 2)) & maskn & g) == 0u) return true;      /* pattern code i has no text counterpart */
+    return ((p ^ (t >> 2)) & maskn & e) == 0u;                /* one extra text code before pattern code i */
+}
+
+/* Code-filter record of a nomination unit (two dwords per key, built by apm_cf_record below):
+ *   rx = first np <= 15 partner codes, read AWAY from the exact part (side 2: the partner's last byte first) | side << 30
+ *   ry = codes of the exact part's bytes 8..15 (16 bits) | np << 16 | exact length << 20 (8 bits)
+ * apm_cf_pass: can the unit's nomination predicate (apm_sieve.hip, stage1) hold at a text position, judged by codes
+ * alone?  c0 = codes of the 16 text bytes from the position on; tw = codes of the 16 text bytes next to the exact part on
+ * the partner's side, read away from it (side 1: from position + exact length on; side 2: the bytes in front of the
+ * position, last one first); `visible` false = those bytes are out of the caller's reach, the partner is not judged.
+ * Never false when stage1 is true. */
+APM_HD bool apm_cf_pass(uint32_t rx, uint32_t ry, uint32_t c0, uint32_t tw, bool visible) {
+    const uint32_t side = rx >> 30, len = (ry >> 20) & 0xffu; /* (bit 31 of ry: the list flag of the sieve's tables) */
+    const int np = (int)((ry >> 16) & 15u);
+    const uint32_t el = len < 16u ? len : 16u;
+    const uint32_t e2mask = el > 8u ? ((1u << (2u * (el - 8u))) - 1u) : 0u;
+    if ((((c0 >> 16) ^ ry) & e2mask) != 0u) return false; /* bytes 8.. of the exact part */
+    if (side == 0u || !visible) return true;
+    return apm_ext1_codes(rx & 0x3fffffffu, tw, np);
+}
+/* 16 codes in reverse order (code i <-> code 15 - i) */
+APM_HD uint32_t apm_rev_codes(uint32_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t r = __builtin_bitreverse32(w);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((w >> i) & 1u) << (31 - i);
+#endif
+    return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+
+/* ---------------------------------------------------------------------------
  * Host side of the presence bitmaps (plan builder in apm_runtime.hip; tests/host_core_test.cpp checks the
  * constructive enumeration against the brute-force definition).
  *
@@ -155,6 +206,17 @@ struct ApmUnit {
     int poff, plen; /* partner (side != 0) */
     int side;       /* 0 none, 1 partner behind the exact part, 2 in front of it */
 };
+
+/* the unit's code-filter record (apm_cf_pass) */
+inline void apm_cf_record(const uint8_t *pat, const ApmUnit &u, int shift, uint32_t *rx, uint32_t *ry) {
+    auto code = [&](int y) { return (uint32_t)((pat[y] >> shift) & 3); };
+    const int np = u.side ? (u.plen < 15 ? u.plen : 15) : 0;
+    uint32_t p = 0, e2 = 0;
+    for (int i = 0; i < np; ++i) p |= code(u.side == 1 ? u.poff + i : u.poff + u.plen - 1 - i) << (2 * i);
+    for (int i = 8; i < u.len && i < 16; ++i) e2 |= code(u.off + i) << (2 * (i - 8));
+    *rx = p | ((uint32_t)u.side << 30);
+    *ry = e2 | ((uint32_t)np << 16) | ((uint32_t)u.len << 20);
+}
 
 /* can the text codes t[0..vis) (the first vis text bytes behind the exact part) still belong to a text that matches
    the partner codes c[0..n) within one edit?  (bytes beyond vis are unknown = wildcards) */

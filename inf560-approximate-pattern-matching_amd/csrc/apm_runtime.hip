@@ -117,6 +117,10 @@ struct SievePlan {         // ONE text pass (apm_sieve2_kernel) for every per-po
     double rate = 0;                  // expected hits per lookup on uniform codes (bitmap density)
     std::vector<uint32_t> bitmap;     // 32 KiB over the 18-bit code words of 9-byte windows: dword x & 8191, bit x >> 13
     std::vector<VerifyLaunch> launches;
+    // code filter of the sieve (ApmSieve2Args::cf_image): stride 1 and ONE verify launch -- the head of its image + krec
+    std::vector<uint8_t> cf_image;            // tbl | rrec | lrec
+    int cf_o_rrec = 0, cf_o_lrec = 0;
+    int cf_threads = 0, cf_blocks_per_cu = 0; // launch geometry (occupancy query, cached; threads < 0: does not fit a CU)
 };
 
 struct DevVerify {
@@ -162,6 +166,7 @@ struct DeviceState {
     size_t text_cap = 0;
     hipEvent_t ev_stage[32] = {};             // apm_count_file: staging buffer b copied out (this device's stream)
     uint32_t *d_sieve_bmp = nullptr;           // sieve bitmap (32 KiB)
+    uint8_t *d_sieve_cf = nullptr;             // the sieve's code-filter image (SievePlan::cf_image)
     std::vector<DevVerify> verify;
     uint32_t *d_masks = nullptr;               // the sieve's hit masks: one dword per lane and 4 KiB block (n / 16 bytes)
     size_t masks_cap = 0;                      // dwords
@@ -315,6 +320,7 @@ void free_device_plan(DeviceState &ds) {
     if (ds.d_trivial) hipFree(ds.d_trivial), ds.d_trivial = nullptr;
     if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
     if (ds.d_sieve_bmp) hipFree(ds.d_sieve_bmp), ds.d_sieve_bmp = nullptr;
+    if (ds.d_sieve_cf) hipFree(ds.d_sieve_cf), ds.d_sieve_cf = nullptr;
     for (auto &v : ds.verify) {
         if (v.d_descs) hipFree(v.d_descs);
         if (v.d_image) hipFree(v.d_image);
@@ -479,7 +485,7 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
         // (code word, key) pairs in rank order: the verify kernel keeps the words as dword x & 2047, bit x >> 11
         auto rank_key = [](uint32_t x) { return ((x & 2047u) << 5) | (x >> 11); };
         std::vector<uint64_t> wk;
-        std::vector<uint32_t> kext;
+        std::vector<uint32_t> kext, krec;
         for (size_t kid = 0; kid < units.size(); ++kid) {
             const ApmUnit &u = units[kid];
             const ApmPatDesc &dd = V.descs[V.kinfo[kid] & 0xfffu];
@@ -502,6 +508,10 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             // partner length << 24 (31 = beyond 16) | side << 29
             kext.push_back((uint32_t)(dd.byte_off + (uint32_t)u.off) | (std::min<uint32_t>((uint32_t)u.len, 255u) << 16) |
                            ((u.plen > 16 ? 31u : (uint32_t)u.plen) << 24) | ((uint32_t)u.side << 29));
+            uint32_t rx, ry;
+            apm_cf_record(V.bytes.data() + dd.byte_off, u, S.code_shift, &rx, &ry);
+            krec.push_back(rx);
+            krec.push_back(ry);
         }
         std::sort(wk.begin(), wk.end());
         wk.erase(std::unique(wk.begin(), wk.end()), wk.end());
@@ -546,7 +556,44 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
         }
         V.o_pat = append(V.bytes.data(), V.bytes.size());
         S.m_max = std::max(S.m_max, V.m_max);
+        // the sieve's code filter works on ONE key numbering: built for the set's first launch, dropped below if there are more
+        if (stride == 1 && S.launches.empty()) {
+            std::vector<uint32_t> tbl(4096), rrec, lrec;
+            for (int w = 0; w < 2048; ++w) { tbl[2 * w] = bmp16[w]; tbl[2 * w + 1] = prefix[w]; }
+            for (size_t i = 0; i < wk.size();) { // (rank order, as r2s above)
+                size_t j = i;
+                while (j < wk.size() && (wk[j] >> 32) == (wk[i] >> 32)) ++j;
+                if (j - i == 1) {
+                    const uint32_t kid = (uint32_t)(wk[i] & 0x7fffu);
+                    rrec.push_back(krec[2 * kid]);
+                    rrec.push_back(krec[2 * kid + 1]);
+                } else {
+                    rrec.push_back(0xC0000000u | (uint32_t)(lrec.size() / 2));
+                    rrec.push_back(0u);
+                    for (size_t z = i; z < j; ++z) {
+                        const uint32_t kid = (uint32_t)(wk[z] & 0x7fffu);
+                        lrec.push_back(krec[2 * kid]);
+                        lrec.push_back(krec[2 * kid + 1] | (z + 1 == j ? 0x80000000u : 0u));
+                    }
+                }
+                i = j;
+            }
+            auto cf_append = [&](const std::vector<uint32_t> &v) {
+                const size_t at = S.cf_image.size(), bytes = v.size() * 4;
+                S.cf_image.resize(at + ((bytes + 15) & ~(size_t)15) + 16, 0); // (+16: a lane without a word reads record 0)
+                if (bytes) memcpy(S.cf_image.data() + at, v.data(), bytes);
+                return (int)at;
+            };
+            S.cf_image.clear();
+            cf_append(tbl);
+            S.cf_o_rrec = cf_append(rrec);
+            S.cf_o_lrec = cf_append(lrec);
+        }
         S.launches.push_back(std::move(V));
+    }
+    {
+        static const int cf_env = getenv("APM_SIEVE_CF") ? atoi(getenv("APM_SIEVE_CF")) : 1;
+        if (!cf_env || S.launches.size() != 1) S.cf_image.clear();
     }
     // the sieve's bitmap.  Stride 1: over 9-byte windows at EVEN positions -- a key window may start at the even position
     // (the unit's own nine-byte words, apm_enum_unit_windows with W = 9) or at the odd one behind it (its 16-bit word x,
@@ -947,6 +994,7 @@ int build_plan(apm_ctx *ctx) {
         HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
         if (ctx->sieve.on) {
             if ((rc = upload_vec(ctx, &ds.d_sieve_bmp, ctx->sieve.bitmap))) return rc;
+            if (!ctx->sieve.cf_image.empty() && (rc = upload_vec(ctx, &ds.d_sieve_cf, ctx->sieve.cf_image))) return rc;
             ds.verify.resize(ctx->sieve.launches.size());
             for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
                 const VerifyLaunch &V = ctx->sieve.launches[v];
@@ -1210,6 +1258,21 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
             sv.code_shift = ctx->sieve.code_shift;
             sv.stride = ctx->sieve.stride;
             sv.masks = ds.d_masks;
+            if (!ctx->sieve.cf_image.empty() && ds.d_sieve_cf) { // second stage of the sieve: the code filter
+                SievePlan &S = ctx->sieve;
+                if (!S.cf_threads) {
+                    S.cf_blocks_per_cu = apm_sieve2cf_geometry((int)S.cf_image.size(), &S.cf_threads);
+                    if (S.cf_blocks_per_cu < 1) S.cf_threads = -1; // does not fit a CU
+                }
+                if (S.cf_threads >= 64) {
+                    sv.cf_image = reinterpret_cast<const uint4 *>(ds.d_sieve_cf);
+                    sv.cf_len = (int)S.cf_image.size();
+                    sv.cf_o_rrec = S.cf_o_rrec;
+                    sv.cf_o_lrec = S.cf_o_lrec;
+                    sv.cf_threads = S.cf_threads;
+                    sv.cf_blocks_per_cu = S.cf_blocks_per_cu;
+                }
+            }
             if (tails_pending) { // the truncated tail windows ride as extra workgroups beside the scan
                 sv.n_tail = (int)ctx->stails.descs.size();
                 sv.tail = ta;
@@ -2029,6 +2092,8 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     if (n == "sieve_on") { *value = ctx->sieve.on ? 1 : 0; return APM_OK; }
     if (n == "sieve_rate") { *value = ctx->sieve.rate; return APM_OK; }
     if (n == "sieve_fused") { *value = ds.last_fused ? 1 : 0; return APM_OK; }
+    if (n == "sieve_cf") { *value = (ctx->sieve.on && !ctx->sieve.cf_image.empty() && ctx->sieve.cf_threads >= 64) ? (double)ctx->sieve.cf_threads : 0.0; return APM_OK; } // (after a call: workgroup size of the code-filter form, 0 = plain sieve)
+    if (n == "sieve_cf_bytes") { *value = (double)ctx->sieve.cf_image.size(); return APM_OK; }
     if (n == "sieve_stride") { *value = ctx->sieve.on ? (double)ctx->sieve.stride : 0.0; return APM_OK; }
     if (n == "sieve_mask_bytes") { *value = (double)ds.last_mask_blocks * 256.0; return APM_OK; }
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }

@@ -35,10 +35,26 @@ struct ApmSieve2Args {
     int n_main_blocks;          /* set by the launcher: scanning workgroups */
     int n_tail;                 /* extra workgroups, one per pattern with truncated tail windows (they run beside the scan) */
     ApmTailArgs tail;
+    /* CODE FILTER (stride 1, one verify launch): the sieve's second stage.  A lookup hit says "some key's 8-byte window
+       may start here or at the odd position behind"; before its bit goes into the masks the wave identifies the key(s) by
+       rank and tests, on the 2-bit codes it holds for the block (a wave-private LDS copy, 16 bytes of halo in front and
+       32 behind), what the verify launch would test first on the bytes: bytes 8..15 of the exact part, and the partner
+       within one edit (apm_cf_pass in apm_core.h).  A superset of the nomination predicate survives -- on DNA exactly
+       the predicate: cfg5 21.6 M hits per GiB -> 10.6 K, and the verify launch no longer re-reads the text to reject
+       them.  cf_image = NULL: no second stage.
+       cf_image (16-byte aligned parts): tbl: uint2[2048] = {dword x & 2047 of the bitmap over the 16-bit code words of
+       8-byte windows (bit x >> 11), set bits in the dwords before it} | rrec at cf_o_rrec: uint2 per set bit in rank
+       order = the code-filter record of the word's key (apm_cf_record), or, for a word that several keys share,
+       {3 << 30 | index into lrec, 0} | lrec at cf_o_lrec: their records one after the other, bit 31 of .y = last */
+    const uint4 *cf_image;
+    int cf_len, cf_o_rrec, cf_o_lrec;
+    int cf_threads, cf_blocks_per_cu; /* launch geometry of the code-filter form (apm_sieve2cf_geometry) */
 #ifdef APM_MEASURE
     int skip_mask;
 #endif
 };
+#define APM_CF_WAVE_BYTES 1552  /* per wave: code strip 260 dwords | survivor masks 64 dwords | hit ring 128 x u16 */
+int apm_sieve2cf_geometry(int cf_len, int *threads); /* workgroups per CU; *threads = workgroup size (0: does not fit) */
 
 struct ApmVerifyArgs {
     const uint8_t *text;        /* 16-byte aligned */

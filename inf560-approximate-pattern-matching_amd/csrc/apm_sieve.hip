@@ -51,17 +51,21 @@ __device__ __forceinline__ uint32_t apm_udot4(uint32_t a, uint32_t b) {
 // ---------------------------------------------------------------------------
 // SIEVE
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSieve2Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// CF: with the code filter (ApmSieve2Args::cf_image) -- workgroups of blockDim.x threads, LDS = bitmap | cf image | wave areas
+template <bool CF>
+__device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t *smem) {
+    const int THREADS = CF ? (int)blockDim.x : APM_SIEVE2_BLOCK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if ((int)blockIdx.x >= a.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
-    for (int i = tid; i < 2048; i += APM_SIEVE2_BLOCK) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
+    for (int i = tid; i < 2048; i += THREADS) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
+    if constexpr (CF)
+        for (int i = tid; i < (a.cf_len >> 4); i += THREADS) reinterpret_cast<uint4 *>(smem + 32768)[i] = a.cf_image[i];
     __syncthreads();
-    const int64_t W = (int64_t)a.n_main_blocks * (APM_SIEVE2_BLOCK / 64);
+    const int64_t W = (int64_t)a.n_main_blocks * (THREADS / 64);
     const int64_t nch = a.nchunks;
 
     // 16 bytes per lane and chunk; `tl`: the 8 bytes behind the chunk (one address for the whole wave).  Chunks behind the
@@ -82,6 +86,16 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSiev
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (lim > 0 ? g : 0), 0, (int)nrec, 0x00020000);
         tl = __builtin_amdgcn_raw_buffer_load_b64(rs, 0, 0, 0);
+    };
+    // CF: the halo of the block that starts at chunk cc -- lanes 0, 1: the 32 bytes behind it, lane 2: the 16 bytes in front
+    // of it, lane 3 and up: zeros (one load; the resource spans the whole shard: < 4 GiB, zeros outside, and a position in
+    // front of the shard wraps to a huge offset = zeros, as for every verify path)
+    const __amdgpu_buffer_rsrc_t rs_all =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
+    auto load_halo = [&](int64_t cc, u32x4 &hl) __attribute__((always_inline)) {
+        const uint32_t g = (uint32_t)(a.tile0 + cc * 1024);
+        const uint32_t off = lane < 2 ? g + 4096u + 16u * (uint32_t)lane : (lane == 2 ? g - 16u : 0xfffffff0u);
+        hl = __builtin_amdgcn_raw_buffer_load_b128(rs_all, (int)off, 0, 0);
     };
     // 4 bytes -> 8 code bits (byte z in bits 2z..): shift + and + one v_dot4_u32_u8 with the byte weights 1, 4, 16, 64
     const uint32_t cs = (uint32_t)a.code_shift;
@@ -107,21 +121,100 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSiev
 #endif
         return cc < nch ? hits : 0u;
     };
-    int64_t c = ((int64_t)blockIdx.x * (APM_SIEVE2_BLOCK / 64) + wv) * 4; // four neighbouring chunks per wave
-    u32x4 r0, r1, r2, r3;
+
+    // ---- CODE FILTER (see ApmSieve2Args::cf_image): which of the block's lookup hits can be a nomination at all ----
+    const uint2 *cf_tbl = reinterpret_cast<const uint2 *>(smem + 32768);
+    const uint2 *cf_rrec = reinterpret_cast<const uint2 *>(smem + 32768 + a.cf_o_rrec);
+    const uint2 *cf_lrec = reinterpret_cast<const uint2 *>(smem + 32768 + a.cf_o_lrec);
+    uint32_t *st = reinterpret_cast<uint32_t *>(smem + 32768 + a.cf_len + wv * APM_CF_WAVE_BYTES); // the block's codes: dword 0 =
+                                                                 // the 16 bytes in front, 1..256 the block, 257..258 the 32 behind, 259 zero
+    uint32_t *mk = st + 260;                                     // surviving hit masks, one dword per lane
+    uint16_t *rq = reinterpret_cast<uint16_t *>(mk + 64);        // ring of hits: even position / 2 inside the block | 2048: the odd position only
+    // hm: the lane's hit mask of the block (bit 8 j + t = lookup t of chunk j); sc[j]: the codes of its 16 bytes of chunk j;
+    // hc: codes of the halo bytes this lane loaded.  Returns the mask of the hits that pass the filter.
+    auto cf_filter = [&](uint32_t hm, const uint32_t (&sc)[4], uint32_t hc) __attribute__((always_inline)) -> uint32_t {
+        if (!__builtin_amdgcn_ballot_w64(hm != 0u)) return 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st[1 + 64 * j + lane] = sc[j];
+        if (lane < 4) st[lane < 2 ? 257 + lane : (lane == 2 ? 0 : 259)] = hc;
+        mk[lane] = 0u;
+        uint32_t qh = 0, qt = 0; // wave-uniform: the ring holds entries [qh, qt)
+        // nb <= 64 hits, one per lane.  A hit stands for the even position and the odd one behind it: both 16-bit words
+        // are looked up; the lane follows the even one if it is a key word, else the odd one; when both are, the odd
+        // one goes back into the ring as an entry of its own (rare).
+        auto run_batch = [&](uint32_t nb) __attribute__((always_inline)) {
+            const uint32_t ent = rq[(qh + (uint32_t)lane) & 127u];
+            const bool valid = (uint32_t)lane < nb;
+            const uint32_t se = 2u * (ent & 2047u), d = 1u + (se >> 4), she = 2u * (se & 15u); // even byte position inside the block
+            const uint32_t w0 = st[d], w1 = st[d + 1u];
+            const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, she) & 0xffffu, x1 = __builtin_amdgcn_alignbit(w1, w0, she + 2u) & 0xffffu;
+            const uint2 t0 = cf_tbl[x0 & 2047u], t1 = cf_tbl[x1 & 2047u];
+            const bool p0 = valid && !(ent & 2048u) && ((t0.x >> (x0 >> 11)) & 1u), p1 = valid && ((t1.x >> (x1 >> 11)) & 1u);
+            const unsigned long long both = __builtin_amdgcn_ballot_w64(p0 && p1);
+            if (both) { // the odd position waits for a later batch (the ring has room: at most 63 + 64 entries are ever pending)
+                const uint32_t idx = qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(both >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)both, 0u));
+                if (p0 && p1) rq[idx & 127u] = (uint16_t)(ent | 2048u);
+                qt += (uint32_t)__builtin_popcountll(both);
+            }
+            bool act = p0 || p1;
+            const uint32_t s = se + (p0 ? 0u : 1u); // the position this lane judges
+            const uint32_t c0 = __builtin_amdgcn_alignbit(w1, w0, she + (p0 ? 0u : 2u)); // codes of the 16 bytes from s on
+            const uint32_t x = p0 ? x0 : x1, word = p0 ? t0.x : t1.x, pre = p0 ? t0.y : t1.y, bit = x >> 11;
+            uint2 rec = cf_rrec[act ? pre + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u)) : 0u];
+            uint32_t li = 0; // index of the next record of the word's key list
+            bool in_list = false;
+            if ((rec.x >> 30) == 3u) { li = rec.x & 0xffffu; in_list = true; rec = cf_lrec[li]; ++li; }
+            while (__builtin_amdgcn_ballot_w64(act)) {
+                const uint32_t side = rec.x >> 30;
+                const uint32_t uu = side == 2u ? s : s + 16u + ((rec.y >> 20) & 0xffu); // 16 + the partner's text position
+                const bool vis = uu <= 4128u;
+                const uint32_t ua = vis ? uu : 16u;
+                uint32_t tw = __builtin_amdgcn_alignbit(st[(ua >> 4) + 1u], st[ua >> 4], 2u * (ua & 15u));
+                if (side == 2u) tw = apm_rev_codes(tw);
+                const bool ok = apm_cf_pass(rec.x, rec.y, c0, tw, vis);
+                if (act && ok) {
+                    atomicOr(&mk[(s >> 4) & 63u], 1u << (8u * (s >> 10) + ((s & 15u) >> 1)));
+                    act = false;
+                } else if (act) {
+                    if (!in_list || (rec.y >> 31)) act = false;
+                    else { rec = cf_lrec[li]; ++li; }
+                }
+            }
+        };
+        while (__builtin_amdgcn_ballot_w64(hm != 0u)) {
+            const bool has = hm != 0u;
+            const uint32_t t = has ? (uint32_t)__builtin_ctz(hm) : 0u;
+            hm &= hm - 1u;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+            const uint32_t idx = qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (has) rq[idx & 127u] = (uint16_t)(512u * (t >> 3) + 8u * (uint32_t)lane + (t & 7u));
+            qt += (uint32_t)__builtin_popcountll(mask);
+            while (qt - qh >= 64u) { run_batch(64u); qh += 64u; }
+        }
+        while (qt != qh) { const uint32_t nb = qt - qh < 64u ? qt - qh : 64u; run_batch(nb); qh += nb; }
+        return mk[lane];
+    };
+
+    int64_t c = ((int64_t)blockIdx.x * (THREADS / 64) + wv) * 4; // four neighbouring chunks per wave
+    u32x4 r0, r1, r2, r3, hl;
     v2u32 tl;
     load_chunk(c, r0);
     load_chunk(c + 1, r1);
     load_chunk(c + 2, r2);
     load_chunk(c + 3, r3);
-    load_tail(c + 4, tl);
+    if constexpr (CF) load_halo(c, hl);
+    else load_tail(c + 4, tl);
     for (; c < nch; c += 4 * W) {
-        const uint32_t s0 = pack16(r0), s1 = pack16(r1), s2 = pack16(r2), s3 = pack16(r3), s4 = pack4(tl.x) | (pack4(tl.y) << 8);
+        const uint32_t s0 = pack16(r0), s1 = pack16(r1), s2 = pack16(r2), s3 = pack16(r3);
+        uint32_t s4;
+        if constexpr (CF) s4 = pack16(hl); // (lane 0: the low half = the 8 bytes behind the block)
+        else s4 = pack4(tl.x) | (pack4(tl.y) << 8);
         load_chunk(c + 4 * W, r0);
         load_chunk(c + 4 * W + 1, r1);
         load_chunk(c + 4 * W + 2, r2);
         load_chunk(c + 4 * W + 3, r3);
-        load_tail(c + 4 * W + 4, tl);
+        if constexpr (CF) load_halo(c + 4 * W, hl);
+        else load_tail(c + 4 * W + 4, tl);
         // (chunk by chunk: letting the scheduler interleave the 32 lookups costs more registers than the 8 waves per SIMD leave)
         const uint32_t h0 = hit_bits(s0, (uint32_t)__builtin_amdgcn_readfirstlane((int)s1), c);
         __builtin_amdgcn_sched_barrier(0);
@@ -131,8 +224,25 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSiev
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t h3 = hit_bits(s3, (uint32_t)__builtin_amdgcn_readfirstlane((int)s4), c + 3);
         // the block's hit masks: one coalesced 256-byte store per wave and 4 KiB (see ApmSieve2Args::masks)
-        a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = (h0 >> 24) | ((h1 >> 24) << 8) | ((h2 >> 24) << 16) | (h3 & 0xff000000u);
+        uint32_t hm = (h0 >> 24) | ((h1 >> 24) << 8) | ((h2 >> 24) << 16) | (h3 & 0xff000000u);
+        if constexpr (CF) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t sc[4] = {s0, s1, s2, s3};
+            hm = cf_filter(hm, sc, s4);
+        }
+        a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = hm;
     }
+}
+
+__global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSieve2Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    apm_sieve2_body<false>(a, smem);
+}
+
+// the code-filter form: workgroups of up to 1024 threads share the tables (2 x 16 waves fill a CU)
+__global__ __launch_bounds__(1024, 8) void apm_sieve2cf_kernel(ApmSieve2Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    apm_sieve2_body<true>(a, smem);
 }
 
 // Sampled form (stride 8): every key piece is >= 15 bytes long and therefore contains an 8-byte block that starts at a
@@ -186,18 +296,62 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve8_kernel(ApmSiev
     }
 }
 
+static size_t apm_sieve2cf_lds_bytes(int cf_len, int threads) {
+    return (size_t)32768 + (size_t)cf_len + (size_t)(threads / 64) * APM_CF_WAVE_BYTES;
+}
+
+// workgroup size (a multiple of 64) and workgroups per CU that put the most waves on a CU for this code-filter image
+int apm_sieve2cf_geometry(int cf_len, int *threads) {
+    const void *fn = (const void *)apm_sieve2cf_kernel;
+    int best_waves = 0, best_blocks = 0;
+    *threads = 0;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef APM_MEASURE
+    static const int forced = getenv("APM_CF_THREADS") ? atoi(getenv("APM_CF_THREADS")) : 0;
+#else
+    constexpr int forced = 0;
+#endif
+    for (int t = 1024; t >= 256; t -= 64) {
+        if (forced && t != forced) continue;
+        const size_t lds = apm_sieve2cf_lds_bytes(cf_len, t);
+        if (lds > (size_t)160 * 1024) continue;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, t, lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            continue;
+        }
+        if (per_cu * (t / 64) > best_waves) { // (ties: the bigger workgroup, fewer copies of the tables)
+            best_waves = per_cu * (t / 64);
+            best_blocks = per_cu;
+            *threads = t;
+        }
+    }
+    return best_blocks;
+}
+
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
     if (a.nchunks <= 0) return hipSuccess;
-    const size_t lds = 32768;
-    const int64_t want = (a.nchunks + 4 * (APM_SIEVE2_BLOCK / 64) - 1) / (4 * (APM_SIEVE2_BLOCK / 64));
-    const int64_t cap = (int64_t)n_cu * 4; // = the kernel's launch bound (4 x 512 threads per CU; 4 x 32 KiB of LDS)
-    const int64_t nb = want < cap ? want : cap;
     ApmSieve2Args args = a;
-    args.n_main_blocks = (int)nb;
 #ifdef APM_MEASURE
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
 #endif
     void *kargs[] = {&args};
+    if (a.stride != 8 && a.cf_image) { // the code-filter form
+        const int threads = a.cf_threads, wpb = threads / 64;
+        if (threads < 128 || threads > 1024 || (threads & 63) || a.cf_blocks_per_cu < 1) return hipErrorInvalidValue;
+        const size_t lds = apm_sieve2cf_lds_bytes(a.cf_len, threads);
+        const int64_t want = (a.nchunks + 4 * wpb - 1) / (4 * wpb);
+        const int64_t cap = (int64_t)n_cu * a.cf_blocks_per_cu;
+        const int64_t nb = want < cap ? want : cap;
+        args.n_main_blocks = (int)nb;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)apm_sieve2cf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); // (per device)
+        return hipLaunchKernel((const void *)apm_sieve2cf_kernel, dim3((unsigned)(nb + a.n_tail)), dim3((unsigned)threads), kargs, lds, s);
+    }
+    const size_t lds = 32768;
+    const int64_t want = (a.nchunks + 4 * (APM_SIEVE2_BLOCK / 64) - 1) / (4 * (APM_SIEVE2_BLOCK / 64));
+    const int64_t cap = (int64_t)n_cu * 4; // = the kernel's launch bound (4 x 512 threads per CU; 4 x 32 KiB of LDS)
+    const int64_t nb = want < cap ? want : cap;
+    args.n_main_blocks = (int)nb;
     if (a.stride == 8)
         return hipLaunchKernel((const void *)apm_sieve8_kernel, dim3((unsigned)(nb + a.n_tail)), dim3(APM_SIEVE2_BLOCK), kargs, 8192, s);
     return hipLaunchKernel((const void *)apm_sieve2_kernel, dim3((unsigned)(nb + a.n_tail)), dim3(APM_SIEVE2_BLOCK), kargs, lds, s);
@@ -493,7 +647,10 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
         return true;
     };
     // masks of the block in hand and of the AHEAD blocks after it (sparse sampled lists are bound by this chain of loads)
-    constexpr int AHEAD = FUSED ? 1 : (SAMPLED ? 4 : 1);
+#ifndef APM_VERIFY_AHEAD
+#define APM_VERIFY_AHEAD 4 /* mask rows in flight per wave in front of the block in hand, per-position sets (with the code filter most rows are empty: the walk is a chain of loads) */
+#endif
+    constexpr int AHEAD = FUSED ? 1 : (SAMPLED ? 4 : APM_VERIFY_AHEAD);
     constexpr uint32_t NONE = 0xffffffffu;
     uint32_t hm = 0, hm_q[AHEAD], hb_q[AHEAD]; // hb_q: their block numbers (wave-uniform)
     if constexpr (!FUSED) {
@@ -786,9 +943,11 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
 #endif
     args.work_groups = std::min<long>(APM_WORK_GROUPS, (long)args.n_blocks * (threads / 64));
-    args.work_epoch = (*work_epoch)++; // (only launches that run advance it: each zeroes the counter set of the next)
+    args.work_epoch = *work_epoch;
     void *kargs[] = {&args};
-    return hipLaunchKernel(fn, dim3((unsigned)args.n_blocks), dim3((unsigned)threads), kargs, apm_verify_lds_bytes_t(a, threads), s);
+    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)args.n_blocks), dim3((unsigned)threads), kargs, apm_verify_lds_bytes_t(a, threads), s);
+    if (e == hipSuccess) ++*work_epoch; // only a launch that runs advances it: launch e zeroes the counter set launch e + 1 uses
+    return e;
 }
 
 // ---------------------------------------------------------------------------
@@ -864,7 +1023,9 @@ hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, 
 #endif
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); // (per device: the geometry query ran on one)
     args.v.work_groups = (int)std::min<int64_t>(APM_WORK_GROUPS, nb * (threads / 64));
-    args.v.work_epoch = (*work_epoch)++;
+    args.v.work_epoch = *work_epoch;
     void *kargs[] = {&args};
-    return hipLaunchKernel(fn, dim3((unsigned)(nb + a.s.n_tail)), dim3((unsigned)threads), kargs, lds, s);
+    const hipError_t e = hipLaunchKernel(fn, dim3((unsigned)(nb + a.s.n_tail)), dim3((unsigned)threads), kargs, lds, s);
+    if (e == hipSuccess) ++*work_epoch; // (as in apm_launch_verify)
+    return e;
 }

@@ -182,6 +182,90 @@ int main() {
         if (words_gen > words_def * 3 / 2 + 1000) { printf("constructive enumeration too loose: %ld vs %ld\n", words_gen, words_def); bad++; }
         if (positives < 50000) { printf("unit window test saw too few positives\n"); bad++; }
     }
+    // the sieve's code filter (apm_cf_record / apm_cf_pass / apm_ext1_codes in apm_core.h): never false where the
+    // byte-level nomination predicate holds, whatever the alphabet; on ACGT (codes = bytes) with the whole unit inside
+    // the record (exact part <= 16 bytes, partner <= 15) it IS the predicate
+    {
+        auto ext1_loop = [](const unsigned char *pb, const unsigned char *tb, int n, int dir) { // dir -1: both read backwards
+            auto P = [&](int i) { return pb[dir * i]; };
+            auto T = [&](int i) { return tb[dir * i]; };
+            int i = 0;
+            while (i < n && T(i) == P(i)) ++i;
+            if (i >= n - 1) return true;
+            bool ok = true;
+            for (int j = i + 1; j < n && ok; ++j) ok = T(j) == P(j);
+            if (ok) return true;
+            ok = true;
+            for (int j = i + 1; j < n && ok; ++j) ok = T(j - 1) == P(j);
+            if (ok) return true;
+            ok = true;
+            for (int j = i; j < n && ok; ++j) ok = T(j + 1) == P(j);
+            return ok;
+        };
+        long pos = 0, neg_exact = 0, rejected = 0;
+        for (int it = 0; it < 400000; it++) {
+            const char *alphabet = (it % 3 != 1) ? "ACGT" : ((it % 2) ? "ACGTN\n" : "abcdefgh");
+            const bool dna = it % 3 != 1;
+            const int na = (int)strlen(alphabet), shift = dna ? 1 : (it % 2 ? 1 : 0);
+            unsigned char pat[64];
+            for (int i = 0; i < 64; i++) pat[i] = (unsigned char)alphabet[rand() % na];
+            ApmUnit u;
+            u.len = (it % 5 == 0) ? 0 : 1 + rand() % 20;
+            u.side = (u.len == 0) ? 1 : rand() % 3;
+            u.plen = 1 + rand() % 20;
+            if (u.side == 2) { u.poff = 0; u.off = u.plen; }
+            else { u.off = rand() % 4; u.poff = u.off + u.len; }
+            unsigned char text[96];
+            for (int i = 0; i < 96; i++) text[i] = (unsigned char)alphabet[rand() % na];
+            const int s = 40;
+            if (rand() % 4) { // plant the unit with up to one edit in the partner (and sometimes one more edit anywhere)
+                for (int i = 0; i < u.len; i++) text[s + i] = pat[u.off + i];
+                const int mode = rand() % 4, e = rand() % u.plen;
+                if (u.side == 1) {
+                    int w = s + u.len;
+                    for (int i = 0; i < u.plen; i++) {
+                        if (mode == 1 && i == e) { text[w++] = (unsigned char)alphabet[rand() % na]; continue; }
+                        if (mode == 2 && i == e) continue;
+                        if (mode == 3 && i == e) text[w++] = (unsigned char)alphabet[rand() % na];
+                        text[w++] = pat[u.poff + i];
+                    }
+                } else if (u.side == 2) {
+                    int w = s - 1;
+                    for (int i = u.plen - 1; i >= 0; i--) {
+                        if (mode == 1 && i == e) { text[w--] = (unsigned char)alphabet[rand() % na]; continue; }
+                        if (mode == 2 && i == e) continue;
+                        if (mode == 3 && i == e) text[w--] = (unsigned char)alphabet[rand() % na];
+                        text[w--] = pat[u.poff + i];
+                    }
+                }
+                if (rand() % 3 == 0) text[s - 20 + rand() % 50] = (unsigned char)alphabet[rand() % na];
+            }
+            bool pred = memcmp(text + s, pat + u.off, (size_t)u.len) == 0;
+            if (pred && u.side == 1) pred = ext1_loop(pat + u.poff, text + s + u.len, u.plen, 1);
+            if (pred && u.side == 2) pred = ext1_loop(pat + u.poff + u.plen - 1, text + s - 1, u.plen, -1);
+            uint32_t rx, ry, c0 = 0, tw = 0;
+            apm_cf_record(pat, u, shift, &rx, &ry);
+            auto code = [&](int p) { return (uint32_t)((text[p] >> shift) & 3); };
+            for (int i = 0; i < 16; i++) c0 |= code(s + i) << (2 * i);
+            for (int i = 0; i < 16; i++) tw |= code(u.side == 2 ? s - 16 + i : s + u.len + i) << (2 * i);
+            if (u.side == 2) tw = apm_rev_codes(tw);
+            const bool got = apm_cf_pass(rx, ry, c0, tw, true);
+            // the 8-byte window word is the sieve's business: here only the filter proper
+            if (pred) {
+                pos++;
+                if (!got) { bad++; if (bad < 5) printf("code filter rejects a true nomination (len %d plen %d side %d)\n", u.len, u.plen, u.side); }
+                if (!apm_cf_pass(rx, ry, c0, 0u, false)) { bad++; if (bad < 5) printf("code filter (partner out of reach) rejects a true nomination\n"); }
+            } else if (dna && u.len <= 16 && (u.side == 0 || u.plen <= 15)) {
+                // (a mismatch inside the first 8 bytes of the exact part is the sieve bitmap's to see, not the filter's)
+                if (memcmp(text + s, pat + u.off, (size_t)std::min(u.len, 8)) == 0) {
+                    neg_exact++;
+                    if (got) { bad++; if (bad < 5) printf("code filter passes a false nomination on ACGT (len %d plen %d side %d)\n", u.len, u.plen, u.side); }
+                    else rejected++;
+                }
+            }
+        }
+        if (pos < 100000 || rejected < 10000) { printf("code filter test saw too few cases (%ld positives, %ld exact negatives, %ld rejected)\n", pos, neg_exact, rejected); bad++; }
+    }
     // synthetic generator: bytes are ACGT, deterministic
     for (uint64_t i = 0; i < 1000; i++) {
         const uint8_t b = apm_synth_byte(i, 0x5EED0002ull);

@@ -331,6 +331,70 @@ def _counts_from(raw, P):
     return [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(P)]
 
 
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+def test_the_real_8gib_workloads_range_by_range(apm, cfg):
+    """BASELINE.json configs[3..4] as they are: ONE text of 2^33 bytes, the pattern set made for THAT text
+    (make_patterns(n = 2^33): occurrences planted all over the 8 GiB), cut by apm_shard_range into the eight owner ranges of
+    an 8-GPU node.  The 8 GiB text is resident on this one GPU; every range is scanned as its rank would scan it (its own text
+    window with the m_max - 1 halo, text_off = the range's global offset, all beyond 4 GiB for the upper half) by AUTO and
+    by the full-DP BITPAR kernel (cfg5: every 8th pattern), pattern by pattern equal; every planted occurrence within k is
+    found by the range that owns its position; and the sum over the ranges equals ONE scan of the whole resident text
+    (which the pipeline cuts into 3 GiB pieces itself).  Checker at this size: BITPAR + the sum property; the CPU oracle
+    anchors the same pattern set at the sizes it can reach (two windows per range here)."""
+    import torch
+    wl = H.workloads()
+    c = wl.CONFIGS[cfg]
+    n, k, seed = c["n"], c["k"], wl.seed_of(c["cid"])
+    assert n == 1 << 33
+    pats, planted = wl.make_patterns(n, c["lens"], k, seed)
+    P = len(pats)
+    m_max = max(len(p) for p in pats)
+    sub = list(range(P)) if P <= 32 else list(range(0, P, 8))       # patterns the full-DP kernel re-evaluates
+    text = torch.empty(n + 4096, dtype=torch.uint8, device="cuda:0")
+    cnt = torch.zeros(P, dtype=torch.int64, device="cuda:0")
+    cnt_sub = torch.zeros(len(sub), dtype=torch.int64, device="cuda:0")
+    with apm.ApmContext(device=0) as c2, apm.ApmContext(device=0) as c3:
+        c2.set_patterns(pats, k)
+        c3.set_patterns([pats[i] for i in sub], k)
+        c3.set_kernel("bitpar")
+        c2.synth_fill_device(text.data_ptr(), 0, n, seed)
+        c2.synchronize()
+        total = [0] * P
+        for r in range(8):
+            ob, oe = apm.shard_range(n, k, r, 8)
+            lo, hi = ob, min(n, oe + m_max - 1)
+            assert oe > ob and (r == 0 or ob % 16 == 0)
+            cnt.zero_(); cnt_sub.zero_()
+            torch.cuda.synchronize()
+            c2.count_shard_device(text.data_ptr() + lo, lo, hi - lo, n, ob, oe, cnt.data_ptr())
+            c3.count_shard_device(text.data_ptr() + lo, lo, hi - lo, n, ob, oe, cnt_sub.data_ptr())
+            c2.synchronize(); c3.synchronize()
+            got, full = cnt.cpu().tolist(), cnt_sub.cpu().tolist()
+            assert [got[i] for i in sub] == full, (cfg, r)
+            for i, (o, d) in enumerate(planted):                      # the planted copy lies in exactly one owner range
+                if d <= k and ob <= o < oe:
+                    assert got[i] >= 1, (cfg, r, i)
+            total = [a + b for a, b in zip(total, got)]
+            # a window of the range against the CPU oracle (as the rank would see it: global offsets >= 4 GiB from r = 4 on)
+            w0, wlen = ob + ((oe - ob) // 2 & ~15) + (5 if r % 2 else 0), 1 << 20
+            host = apm.synth_fill_host(w0, wlen + m_max - 1, seed)
+            want = H.oracle_counts(host, [pats[i] for i in sub], k, banded=True, j_end=wlen)
+            cnt.zero_()
+            torch.cuda.synchronize()
+            c2.count_shard_device(text.data_ptr() + w0, w0, wlen + m_max - 1, n, w0, w0 + wlen, cnt.data_ptr())
+            c2.synchronize()
+            one = cnt.cpu().tolist()
+            assert [one[i] for i in sub] == want, (cfg, r, w0)
+        for cc, (o, d) in zip(total, planted):
+            assert cc >= (1 if d <= k else 0)
+        cnt.zero_()
+        torch.cuda.synchronize()
+        c2.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr())   # the whole text in one call
+        c2.synchronize()
+        assert cnt.cpu().tolist() == total, cfg
+    del text
+
+
 @pytest.mark.parametrize("cfg", ["cfg3", "cfg4", "cfg5"])
 def test_full_size_counts_pinned_by_full_dp_kernel(ctx, apm, cfg):
     """BASELINE cfg3 (1 GiB) and the per-GPU shards of cfg4 / cfg5 (2^33 / 8 = 1 GiB) at FULL size: the counts of
@@ -829,7 +893,8 @@ print(json.dumps(out))
                                  {"APM_FILTER_DMA": "0"}, {"APM_FILTER_STREAM": "2", "APM_FILTER_DMA": "0"},
                                  {"APM_SIEVE": "0"}, {"APM_SIEVE": "0", "APM_FILTER_STREAM": "2"},
                                  {"APM_FUSED": "1"},          # sieve + verify in one kernel for every sieved set (default: sampled sets only)
-                                 {"APM_FUSED": "0"}],         # ... for none
+                                 {"APM_FUSED": "0"},          # ... for none
+                                 {"APM_SIEVE_CF": "0"}],      # the sieve without its second stage (the code filter)
                          ids=lambda e: ",".join("%s=%s" % (k[4:], v) for k, v in e.items()) or "default")
 def test_every_filter_kernel_form_agrees_with_oracle(env):
     """The BANDED path picks between the LDS-tile kernel (LDS-DMA or register-staged) and the wave-autonomous

@@ -51,6 +51,6 @@ for cfg in sorted(os.listdir(G)):
     total = sum(v["bytes_per_launch"] * v["launches_in_run"] for v in per_kernel.values()) / steps
     traffic["%s:%s" % (cfg, bench["config"]["kernel"])] = dict(
         round=rnd, kernel=dom, traffic_bytes=per_kernel[dom_key]["bytes_per_launch"] if dom_key else None,
-        step_traffic_bytes=int(total), algorithmic_bytes=bench["roofline"]["algorithmic_bytes_per_launch"], per_kernel=per_kernel)
+        step_traffic_bytes=int(total), algorithmic_bytes=bench["roofline"].get("algorithmic_bytes_per_step", bench["roofline"].get("algorithmic_bytes_per_launch")), per_kernel=per_kernel)
     print(cfg, dom[:50], per_kernel.get(dom_key, {}).get("bytes_per_launch"), "step", int(total))
 json.dump(traffic, open(traffic_path, "w"), indent=1)
