@@ -143,21 +143,26 @@ APM_HD bool apm_ext1_core16(const uint32_t (&p)[4], const uint32_t (&t)[5], int 
  * strings too, and a prefix of such an alignment has <= 1 edit: the result is a superset of what
  * apm_ext1_core16 accepts for the whole partner -- a filter, never a decision.
  * ------------------------------------------------------------------------- */
-APM_HD bool apm_ext1_codes(uint32_t p, uint32_t t, int n) {
+/* Branch-free: with i = the first mismatching code (bit index i2 = 2 i), g = the bits above code i, e = the bits from code
+ * i on, the three ways to spend the edit leave these mismatch bits, and the answer is "one of them is empty":
+ *   substitution at i                          x0 & g            (also empty when there is no mismatch at all, and when
+ *                                                                 i is the last code: g then lies beyond the n codes)
+ *   pattern code i has no text counterpart     (p ^ t << 2) & g
+ *   one extra text code before pattern code i  (p ^ t >> 2) & e                                                        */
+APM_HD uint32_t apm_ext1_codes_bits(uint32_t p, uint32_t t, int n) {
     const uint32_t maskn = (1u << (2 * n)) - 1u;
     const uint32_t x0 = (p ^ t) & maskn;
-    if (x0 == 0u) return true;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int i2 = (__ffs((int)x0) - 1) & ~1; /* bit index of the first mismatching code */
+    const uint32_t i2 = (uint32_t)__builtin_ctzg(x0, 32) & 30u; /* v_ffbl_b32 + v_and (x0 == 0: any value will do) */
 #else
-    const int i2 = __builtin_ctz(x0) & ~1;
+    const uint32_t i2 = x0 ? ((uint32_t)__builtin_ctz(x0) & 30u) : 0u;
 #endif
-    if (i2 >= 2 * (n - 1)) return true;
-    const uint32_t g = 0xffffffffu << (i2 + 2), e = 0xffffffffu << i2;
-    if ((x0 & g) == 0u) return true;                          /* substitution at i */
-    if (((p ^ (t << 2)) & maskn & g) == 0u) return true;      /* pattern code i has no text counterpart */
-    return ((p ^ (t >> 2)) & maskn & e) == 0u;                /* one extra text code before pattern code i */
+    const uint32_t g = 0xfffffffcu << i2, e = 0xffffffffu << i2;
+    const uint32_t sub = x0 & g, del = (p ^ (t << 2)) & maskn & g, ins = (p ^ (t >> 2)) & maskn & e;
+    const uint32_t m1 = sub < del ? sub : del;
+    return m1 < ins ? m1 : ins; /* v_min3_u32 */
 }
+APM_HD bool apm_ext1_codes(uint32_t p, uint32_t t, int n) { return apm_ext1_codes_bits(p, t, n) == 0u; }
 
 /* Code-filter record of a nomination unit (two dwords per key, built by apm_cf_record below):
  *   rx = first np <= 15 partner codes, read AWAY from the exact part (side 2: the partner's last byte first) | side << 30
@@ -166,15 +171,15 @@ APM_HD bool apm_ext1_codes(uint32_t p, uint32_t t, int n) {
  * alone?  c0 = codes of the 16 text bytes from the position on; tw = codes of the 16 text bytes next to the exact part on
  * the partner's side, read away from it (side 1: from position + exact length on; side 2: the bytes in front of the
  * position, last one first); `visible` false = those bytes are out of the caller's reach, the partner is not judged.
- * Never false when stage1 is true. */
+ * Never false when stage1 is true.  (Branch-free: the kernels run it on partly filled waves.) */
 APM_HD bool apm_cf_pass(uint32_t rx, uint32_t ry, uint32_t c0, uint32_t tw, bool visible) {
     const uint32_t side = rx >> 30, len = (ry >> 20) & 0xffu; /* (bit 31 of ry: the list flag of the sieve's tables) */
     const int np = (int)((ry >> 16) & 15u);
     const uint32_t el = len < 16u ? len : 16u;
     const uint32_t e2mask = el > 8u ? ((1u << (2u * (el - 8u))) - 1u) : 0u;
-    if ((((c0 >> 16) ^ ry) & e2mask) != 0u) return false; /* bytes 8.. of the exact part */
-    if (side == 0u || !visible) return true;
-    return apm_ext1_codes(rx & 0x3fffffffu, tw, np);
+    const uint32_t e2bits = ((c0 >> 16) ^ ry) & e2mask; /* bytes 8.. of the exact part */
+    const uint32_t pbits = (side != 0u && visible) ? apm_ext1_codes_bits(rx & 0x3fffffffu, tw, np) : 0u;
+    return (e2bits | pbits) == 0u;
 }
 /* 16 codes in reverse order (code i <-> code 15 - i) */
 APM_HD uint32_t apm_rev_codes(uint32_t w) {

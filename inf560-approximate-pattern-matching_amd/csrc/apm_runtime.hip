@@ -173,6 +173,9 @@ struct DeviceState {
     int64_t last_mask_blocks = 0;              // blocks the last call's sieve wrote (statistics)
     uint32_t *d_work = nullptr;                // block-distribution counters of the verify / fused launches (ApmVerifyArgs::work)
     int work_epoch = 0;
+    uint32_t *d_blist = nullptr;               // the sieve's list of non-empty blocks (one dword per 4 KiB block at most)
+    size_t blist_cap = 0;
+    int sieve_epoch = 0;                       // which of the two list counters the next sieve launch counts in
     unsigned long long *d_stats = nullptr;     // 8 counters (statistics kernel; measurement build: verify counters)
     bool last_fused = false;                   // the last call used the fused form of the pipeline
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
@@ -1159,6 +1162,7 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 HIP_TRY(ctx, hipMalloc((void **)&ds.d_work, APM_WORK_BYTES));
                 HIP_TRY(ctx, hipMemsetAsync(ds.d_work, 0, APM_WORK_BYTES, ds.stream));
                 ds.work_epoch = 0;
+                ds.sieve_epoch = 0;
             }
             // FUSED form: one kernel per verify group sieves and verifies; the text leaves HBM once, no masks.  Measured on
             // MI355X (profiles/r02/fused_ab.txt): the sampled pipeline gains 15 % (cfg4 0.268 -> 0.228 ms per GiB: its
@@ -1248,6 +1252,17 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 HIP_TRY(ctx, hipMalloc((void **)&ds.d_masks, need * 4));
                 ds.masks_cap = need;
             }
+            if (ds.blist_cap < (size_t)n_mask_blocks + 64) {
+                if (ds.d_blist) {
+                    HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+                    HIP_TRY(ctx, hipFree(ds.d_blist));
+                }
+                ds.d_blist = nullptr;
+                ds.blist_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&ds.d_blist, ((size_t)n_mask_blocks + 64) * 4));
+                ds.blist_cap = (size_t)n_mask_blocks + 64;
+            }
+            static const int blist_env = getenv("APM_SIEVE_BLIST") ? atoi(getenv("APM_SIEVE_BLIST")) : 1; // (A/B aid: 0 = the verify launches walk every mask row)
             ds.last_mask_blocks = n_mask_blocks;
             ApmSieve2Args sv{};
             sv.text = d_text;
@@ -1278,7 +1293,14 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 sv.tail = ta;
                 tails_pending = false;
             }
+            const bool use_blist = blist_env && sv.cf_image != nullptr; // (the list is kept by the code-filter form of the sieve only)
+            if (use_blist) {
+                sv.blist = ds.d_blist;
+                sv.blist_ctr = APM_BLIST_CTR(ds.d_work, ds.sieve_epoch & 1);
+                sv.blist_ctr_next = APM_BLIST_CTR(ds.d_work, (ds.sieve_epoch + 1) & 1);
+            }
             HIP_TRY(ctx, apm_launch_sieve2(sv, ds.n_cu, ds.stream));
+            if (use_blist) ++ds.sieve_epoch; // (a launch that did not run leaves its counter set as it was: still zero)
             { const int nrc = note_launch(ctx, ds, "sieve"); if (nrc) return nrc; }
             for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
                 VerifyLaunch &V = ctx->sieve.launches[v];
@@ -1311,6 +1333,10 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 va.code_shift = ctx->sieve.code_shift;
                 va.stride = ctx->sieve.stride;
                 va.masks = ds.d_masks;
+                if (use_blist) {
+                    va.blist = ds.d_blist;
+                    va.blist_ctr = sv.blist_ctr;
+                }
                 va.tile0 = p_lo;
                 va.n_mask_blocks = n_mask_blocks;
 #ifdef APM_MEASURE
@@ -1768,6 +1794,7 @@ void apm_destroy(apm_ctx *ctx) {
         if (ds.d_masks) hipFree(ds.d_masks);
         if (ds.d_stats) hipFree(ds.d_stats);
         if (ds.d_work) hipFree(ds.d_work);
+        if (ds.d_blist) hipFree(ds.d_blist);
         for (hipEvent_t e : ds.ev_stage) if (e) hipEventDestroy(e);
         for (hipEvent_t e : ds.ev_launch) if (e) hipEventDestroy(e);
         for (hipEvent_t e : {ds.ev_start, ds.ev_kstart, ds.ev_mstart, ds.ev_mstop, ds.ev_stop}) if (e) hipEventDestroy(e);

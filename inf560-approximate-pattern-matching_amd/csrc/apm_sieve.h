@@ -32,6 +32,14 @@ struct ApmSieve2Args {
        written by exactly one wave with one coalesced store: no queue, no atomics, no capacity, nothing to overflow;
        n / 16 bytes. */
     uint32_t *masks;
+    /* list of the blocks with at least one hit (stride 1; NULL: none kept), for the verify launches to walk instead of
+       every mask row: with the code filter most rows are empty (cfg5: 10 K hits in 262 K rows per GiB) and the walk, a chain
+       of dependent loads per wave, was all the verify launch did (0.08 ms).  A wave collects its non-empty block numbers
+       in a register and appends them 64 at a time (one atomic on *blist_ctr per flush); at most one entry per block: the
+       list cannot overflow.  Order is arbitrary.  blist_ctr points at one of two counters the sieve launches alternate
+       between (launch i counts in set i & 1 and zeroes the other for launch i + 1 on the same stream). */
+    uint32_t *blist;
+    uint32_t *blist_ctr, *blist_ctr_next;
     int n_main_blocks;          /* set by the launcher: scanning workgroups */
     int n_tail;                 /* extra workgroups, one per pattern with truncated tail windows (they run beside the scan) */
     ApmTailArgs tail;
@@ -80,6 +88,8 @@ struct ApmVerifyArgs {
                                    of 8, the key list entries carry the block's offset r inside its piece (bits 11..13 of
                                    the 15-bit payload, key id in bits 0..10) and the piece is tested at position - r */
     const uint32_t *masks;      /* see ApmSieve2Args */
+    const uint32_t *blist;      /* see ApmSieve2Args; NULL: every block 0 .. n_mask_blocks - 1 */
+    const uint32_t *blist_ctr;  /* entries of blist */
     int64_t tile0;              /* relative position of block 0 */
     int64_t n_mask_blocks;      /* 4 KiB blocks the sieve wrote masks for */
     int n_blocks;               /* set by the launcher */
@@ -110,10 +120,11 @@ int apm_fused_geometry(const ApmFusedArgs &a, int *threads); /* workgroups per C
 
 #define APM_WORK_GROUPS 32
 #define APM_WORK_STRIDE 64
-#define APM_WORK_BYTES (2 * APM_WORK_GROUPS * APM_WORK_STRIDE * 4)
+#define APM_WORK_BYTES (2 * APM_WORK_GROUPS * APM_WORK_STRIDE * 4 + 2 * APM_WORK_STRIDE * 4) /* ... + the two block-list counters of the sieve */
+#define APM_BLIST_CTR(work, set) ((work) + 2 * APM_WORK_GROUPS * APM_WORK_STRIDE + (set) * APM_WORK_STRIDE)
 #define APM_STATS_WAVES 16384                         /* measurement build: per-wave time stamps behind the 8 counters */
 #define APM_STATS_BYTES (64 + 16 * APM_STATS_WAVES)
-hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s);
+hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s); /* a.blist set: the caller alternates blist_ctr / blist_ctr_next and advances its epoch on success */
 hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks, int *work_epoch, hipStream_t s);
 int apm_verify_geometry(const ApmVerifyArgs &a, int *threads); /* workgroups per CU; *threads = 256 or 512 */
 

@@ -24,7 +24,7 @@
 
 /* tuning constants (each measured on MI355X with tools/ab_libs.sh, one box per comparison) */
 #ifndef APM_WORK_CH
-#define APM_WORK_CH 2u /* blocks per chunk of the dynamic distribution, per-position sets (1, 2, 4: the same within 1 %) */
+#define APM_WORK_CH 8u /* blocks per chunk of the dynamic distribution, per-position sets (2, 8: the same within 3 %; 8 = fewer atomics when most rows are empty) */
 #endif
 #ifndef APM_WORK_CH8
 #define APM_WORK_CH8 8u /* ... sampled sets (8, 16: the same) */
@@ -195,6 +195,17 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
         return mk[lane];
     };
 
+    // the wave's non-empty blocks (ApmSieve2Args::blist): lane i holds the i-th pending block number
+    uint32_t bl_pend = 0, bl_n = 0; // (bl_n wave-uniform)
+    auto bl_flush = [&]() __attribute__((always_inline)) {
+        uint32_t base = 0;
+        if (lane == 0) base = __hip_atomic_fetch_add(a.blist_ctr, bl_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if ((uint32_t)lane < bl_n) a.blist[base + (uint32_t)lane] = bl_pend;
+        bl_n = 0;
+    };
+    if (CF && a.blist && blockIdx.x == 0 && tid == 0) *a.blist_ctr_next = 0u; // (nobody counts in the other set during this launch)
+
     int64_t c = ((int64_t)blockIdx.x * (THREADS / 64) + wv) * 4; // four neighbouring chunks per wave
     u32x4 r0, r1, r2, r3, hl;
     v2u32 tl;
@@ -231,7 +242,15 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
             hm = cf_filter(hm, sc, s4);
         }
         a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = hm;
+        if constexpr (CF) { // (without the filter nearly every block has hits: no list)
+            if (a.blist && __builtin_amdgcn_ballot_w64(hm != 0u)) {
+                if ((uint32_t)lane == bl_n) bl_pend = (uint32_t)(c >> 2);
+                if (++bl_n == 64u) bl_flush();
+            }
+        }
     }
+    if constexpr (CF)
+        if (a.blist && bl_n) bl_flush();
 }
 
 __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSieve2Args a) {
@@ -620,7 +639,11 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     // whole machine, so the groups finish together -- and takes the group's next chunk with one atomic, issued a
     // chunk ahead of its use.  The counters of the NEXT launch are zeroed here (two sets, the host alternates). ----
     constexpr uint32_t CH = SAMPLED ? APM_WORK_CH8 : APM_WORK_CH;
-    const uint32_t NB = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : (uint32_t)a.n_mask_blocks; // 4 KiB blocks in all
+    // 4 KiB blocks in all; with a block list (ApmVerifyArgs::blist) only the listed ones: entry b of the list is the block
+    // -- when the list is short: with most blocks on it (cfg3) the walk over all rows is the shorter chain of loads
+    const uint32_t n_listed = (!FUSED && a.blist != nullptr) ? *a.blist_ctr : 0xffffffffu;
+    const bool listed = n_listed < (uint32_t)a.n_mask_blocks / 4u;
+    const uint32_t NB = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : (listed ? n_listed : (uint32_t)a.n_mask_blocks);
     const uint32_t NC = (NB + CH - 1u) / CH;
     // NG = min(APM_WORK_GROUPS, waves of the launch): no group without a wave.  Workgroups go round the XCDs, so the low
     // bits of the wave number alone would tie a group to one XCD and one wave slot: fold the higher bits in
@@ -648,7 +671,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     };
     // masks of the block in hand and of the AHEAD blocks after it (sparse sampled lists are bound by this chain of loads)
 #ifndef APM_VERIFY_AHEAD
-#define APM_VERIFY_AHEAD 4 /* mask rows in flight per wave in front of the block in hand, per-position sets (with the code filter most rows are empty: the walk is a chain of loads) */
+#define APM_VERIFY_AHEAD 2 /* mask rows in flight per wave in front of the block in hand, per-position sets (1, 2, 4: the same within the box-to-box noise; 4 spills in the 72-register instantiation) */
 #endif
     constexpr int AHEAD = FUSED ? 1 : (SAMPLED ? 4 : APM_VERIFY_AHEAD);
     constexpr uint32_t NONE = 0xffffffffu;
@@ -657,7 +680,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) {
             uint32_t b = NONE;
-            hb_q[i] = it_next(b) ? b : NONE;
+            hb_q[i] = it_next(b) ? (listed ? a.blist[b] : b) : NONE;
             hm_q[i] = hb_q[i] != NONE ? a.masks[(uint64_t)hb_q[i] * 64 + (uint64_t)lane] : 0u;
         }
     }
@@ -737,7 +760,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
                 for (int i = 0; i + 1 < AHEAD; ++i) { hm_q[i] = hm_q[i + 1]; hb_q[i] = hb_q[i + 1]; }
                 {
                     uint32_t b = NONE;
-                    hb_q[AHEAD - 1] = it_next(b) ? b : NONE;
+                    hb_q[AHEAD - 1] = it_next(b) ? (listed ? a.blist[b] : b) : NONE;
                     hm_q[AHEAD - 1] = hb_q[AHEAD - 1] != NONE ? a.masks[(uint64_t)hb_q[AHEAD - 1] * 64 + (uint64_t)lane] : 0u;
                 }
                 continue;

@@ -107,7 +107,8 @@ def test_no_kernel_spills_to_scratch():
             # the next lower occupancy (cfg3: 2.51 vs 2.69 ms), so a small budget is tolerated there and only there.
             tile_banded = "apm_filter_kernel" in name and "ILi0E" not in name
             assert spilled <= (48 if tile_banded else 0), "%s spills %d bytes to scratch" % (name, spilled)
-        elif line.startswith("LDS Size") and ("apm_filter_kernel" in name or "apm_stream_kernel" in name or "apm_sieve2_kernel" in name):
+        elif line.startswith("LDS Size") and any(t in name for t in ("apm_filter_kernel", "apm_stream_kernel", "apm_sieve2_kernel", "apm_sieve2cf_kernel",
+                                                                      "apm_sieve8_kernel", "apm_fused_kernel")):
             # their key bitmap is addressed as a compile-time LDS constant: dynamic LDS must start at 0
             assert int(line.rsplit(":", 1)[1]) == 0, "%s owns static LDS" % name
     assert seen >= 40
