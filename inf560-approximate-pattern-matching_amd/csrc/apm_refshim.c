@@ -99,9 +99,23 @@ void write_kernel_result(int *local_matches, int *d_local_matches) {
 
 /* ---- src/database_over_ranks.cu:137-205 (result in a file-scope global there too, :18) ---- */
 static void *g_db_text;
-static void *g_db_counts; /* nb_patterns x uint64 on the device */
 static int *g_db_init;    /* numberOfMatchesInitialized */
 static int g_db_patterns, g_db_last;
+/* one scan per group of equal-length patterns, enqueued by initializeGPU and collected by getGPUResult: the group's
+   count vector on the device and the pattern slots its entries belong to */
+typedef struct shim_group { void *d_counts; int *slot; int n; } shim_group;
+static shim_group *g_db_groups;
+static int g_db_n_groups;
+
+static void shim_free_groups(apm_ctx *ctx) {
+    for (int i = 0; i < g_db_n_groups; ++i) {
+        if (ctx && g_db_groups[i].d_counts) apm_device_free(ctx, g_db_groups[i].d_counts);
+        free(g_db_groups[i].slot);
+    }
+    free(g_db_groups);
+    g_db_groups = NULL;
+    g_db_n_groups = 0;
+}
 
 int initializeGPU(char *buf, int n_bytes, char **pattern, int nb_patterns, int lastPatternAnalyzedByGPU, int *sizePatterns,
                   int indexFinishMyPieceWithoutExtra, int myRank, int numberProcesses, int indexStartMyPiece,
@@ -115,16 +129,20 @@ int initializeGPU(char *buf, int n_bytes, char **pattern, int nb_patterns, int l
     if (!ctx || g_db_last <= 0) return 1;
     const uint64_t n = n_bytes > 0 ? (uint64_t)n_bytes : 0;
     if (g_db_text) apm_device_free(ctx, g_db_text), g_db_text = NULL;
-    if (g_db_counts) apm_device_free(ctx, g_db_counts), g_db_counts = NULL;
-    if (apm_device_alloc(ctx, &g_db_text, n + 16) != APM_OK || apm_device_alloc(ctx, &g_db_counts, 8 * (uint64_t)nb_patterns) != APM_OK ||
-        apm_device_upload(ctx, g_db_text, buf, n) != APM_OK || apm_device_memset(ctx, g_db_counts, 0, 8 * (uint64_t)nb_patterns) != APM_OK) {
+    shim_free_groups(ctx);
+    if (apm_device_alloc(ctx, &g_db_text, n + 16) != APM_OK || apm_device_upload(ctx, g_db_text, buf, n) != APM_OK) {
         shim_fail("initializeGPU");
         return 1;
     }
     /* searchPattern treats buf[0:end_i) as the whole text of pattern i (database_over_ranks.cu:81-97); end_i depends
-       on m_i only through "+ m_i - 1", so the patterns are scanned in groups of equal length */
+       on m_i only through "+ m_i - 1", so the patterns are scanned in groups of equal length.  Nothing is downloaded
+       here: like the reference's launch (database_over_ranks.cu:180-189) the call returns with the scans enqueued and
+       the host's own share of the patterns (the OpenMP region of database_over_ranks.c) runs beside them; getGPUResult
+       waits.  (With several length groups the plan of group g is replaced while building group g + 1, which waits for
+       group g's kernels: only the last group overlaps the host then.) */
     char *done = (char *)calloc((size_t)g_db_last, 1);
-    for (int i = 0; i < g_db_last && done; ++i) {
+    g_db_groups = (shim_group *)calloc((size_t)g_db_last, sizeof *g_db_groups);
+    for (int i = 0; i < g_db_last && done && g_db_groups; ++i) {
         if (done[i]) continue;
         const int m = sizePatterns[i];
         int n_grp = 0;
@@ -139,21 +157,25 @@ int initializeGPU(char *buf, int n_bytes, char **pattern, int nb_patterns, int l
         if (myRank != numberProcesses - 1) end += m - 1;
         if (end > (long)n) end = (long)n;
         const long start = indexStartMyPiece > 0 ? indexStartMyPiece : 0;
-        uint64_t *host = (uint64_t *)calloc((size_t)n_grp, 8);
         int ok = end > start && approx_factor >= 0;
         if (ok) {
             ok = apm_set_patterns(ctx, n_grp, pats, lens, approx_factor) == APM_OK &&
                  apm_device_alloc(ctx, &d_grp, 8 * (uint64_t)n_grp) == APM_OK &&
                  apm_device_memset(ctx, d_grp, 0, 8 * (uint64_t)n_grp) == APM_OK &&
                  apm_count_shard_device(ctx, g_db_text, 0, (uint64_t)end, (uint64_t)end, (uint64_t)start, (uint64_t)end,
-                                        (uint64_t *)d_grp) == APM_OK &&
-                 apm_device_download(ctx, host, d_grp, 8 * (uint64_t)n_grp) == APM_OK;
+                                        (uint64_t *)d_grp) == APM_OK;
             if (!ok) shim_fail("initializeGPU");
         }
-        for (g = 0; ok && g < n_grp; ++g) /* scatter the group's counts to their pattern slots */
-            if (apm_device_upload(ctx, (char *)g_db_counts + 8 * (size_t)slot[g], &host[g], 8) != APM_OK) shim_fail("initializeGPU");
-        if (d_grp) apm_device_free(ctx, d_grp);
-        free(host); free(pats); free(lens); free(slot);
+        if (ok) {
+            g_db_groups[g_db_n_groups].d_counts = d_grp;
+            g_db_groups[g_db_n_groups].slot = slot;
+            g_db_groups[g_db_n_groups].n = n_grp;
+            ++g_db_n_groups;
+        } else {
+            if (d_grp) apm_device_free(ctx, d_grp);
+            free(slot);
+        }
+        free(pats); free(lens);
     }
     free(done);
     return 1; /* (the reference returns 1 always, database_over_ranks.cu:190) */
@@ -163,10 +185,12 @@ int *getGPUResult(int nb_patterns) {
     int *out = (int *)malloc(sizeof(int) * (size_t)(nb_patterns > 0 ? nb_patterns : 1)); /* caller-owned, as the reference's */
     if (!out) return NULL;
     for (int i = 0; i < nb_patterns; ++i) out[i] = (g_db_init && i < g_db_patterns) ? g_db_init[i] : 0;
-    if (g_ctx && g_db_counts && g_db_last > 0) {
-        uint64_t *c = (uint64_t *)calloc((size_t)g_db_patterns, 8);
-        if (c && apm_device_download(g_ctx, c, g_db_counts, 8 * (uint64_t)g_db_patterns) == APM_OK) {
-            for (int i = 0; i < g_db_last && i < nb_patterns; ++i) out[i] += (int)c[i];
+    for (int gi = 0; g_ctx && gi < g_db_n_groups; ++gi) { /* the downloads wait for the scans initializeGPU enqueued */
+        const shim_group *grp = &g_db_groups[gi];
+        uint64_t *c = (uint64_t *)calloc((size_t)grp->n, 8);
+        if (c && apm_device_download(g_ctx, c, grp->d_counts, 8 * (uint64_t)grp->n) == APM_OK) {
+            for (int g = 0; g < grp->n; ++g)
+                if (grp->slot[g] < nb_patterns) out[grp->slot[g]] += (int)c[g];
         } else {
             shim_fail("getGPUResult");
         }

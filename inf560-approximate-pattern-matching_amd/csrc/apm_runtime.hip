@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
+#include <mutex>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -103,7 +105,7 @@ struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns 
     std::vector<uint32_t> kpart;      // per key: partner offset inside the pattern | partner length << 16
     std::vector<uint32_t> pinfo;      // per pattern: {byte_off | m << 16, id of its first key}
     std::vector<uint8_t> image;       // bitmap16 | prefix | r2s | slots | kext | pattern bytes
-    int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0, o_masks = 0;
+    int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0, o_masks = 0, o_kinfo = 0, o_pinfo = 0;
     int m_max = 0, m_min = 0;
     int blocks_per_cu = 0, threads = 256; // launch geometry (occupancy query, cached)
     int fused_blocks_per_cu = 0, fused_threads = 0; // the same for the fused form (threads < 0: it does not fit a CU)
@@ -239,6 +241,8 @@ int fail(apm_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    static std::mutex mu; // (the per-device staging threads of count_sharded may fail side by side)
+    std::lock_guard<std::mutex> lock(mu);
     if (ctx) ctx->err = buf;
     else g_create_error = buf;
     return code;
@@ -461,7 +465,7 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             const size_t pw = stride == 8 ? us.size() * 8 : count_words(reinterpret_cast<const uint8_t *>(pi.bytes.data()), us);
             // the image must fit a CU's LDS beside the wave buffers of one workgroup, and the slot indices 15 bits:
             // bitmap + prefix (12 KiB), rank -> key and key lists (<= 2 + 2 bytes per word), key records, pattern bytes
-            const size_t est = 12288 + 4 * (n_words + pw) + 4 * (V.kinfo.size() + us.size()) + V.bytes.size() + (size_t)pi.m + 512;
+            const size_t est = 12288 + 4 * (n_words + pw) + 8 * (V.kinfo.size() + us.size()) + 8 * (V.descs.size() + 1) + V.bytes.size() + (size_t)pi.m + 512;
             if (!V.descs.empty() && (V.bytes.size() + (size_t)pi.m > 24576 || V.kinfo.size() + us.size() > (stride == 8 ? 2048u : 8192u) || V.descs.size() >= 4096 ||
                                      est > APM_VERIFY_IMAGE_MAX || n_words + pw >= 0x7000))
                 break;
@@ -558,6 +562,8 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             V.o_masks = append(masks.data(), masks.size());
         }
         V.o_pat = append(V.bytes.data(), V.bytes.size());
+        V.o_kinfo = append(V.kinfo.data(), V.kinfo.size() * 4);
+        V.o_pinfo = append(V.pinfo.data(), V.pinfo.size() * 4);
         S.m_max = std::max(S.m_max, V.m_max);
         // the sieve's code filter works on ONE key numbering: built for the set's first launch, dropped below if there are more
         if (stride == 1 && S.launches.empty()) {
@@ -1199,6 +1205,8 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 va.o_kext = V.o_kext;
                 va.o_pat = V.o_pat;
                 va.o_masks = V.o_masks;
+                va.o_kinfo = V.o_kinfo;
+                va.o_pinfo = V.o_pinfo;
                 va.kinfo = ds.verify[v].d_kinfo;
                 va.pinfo = reinterpret_cast<const uint2 *>(ds.verify[v].d_pinfo);
                 va.kpart = ds.verify[v].d_kpart;
@@ -1321,6 +1329,8 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 va.o_kext = V.o_kext;
                 va.o_pat = V.o_pat;
                 va.o_masks = V.o_masks;
+                va.o_kinfo = V.o_kinfo;
+                va.o_pinfo = V.o_pinfo;
                 va.kinfo = ds.verify[v].d_kinfo;
                 va.pinfo = reinterpret_cast<const uint2 *>(ds.verify[v].d_pinfo);
                 va.kpart = ds.verify[v].d_kpart;
@@ -1574,7 +1584,11 @@ int reduce_counts(apm_ctx *ctx, uint64_t *counts) {
     const size_t G = ctx->devs.size();
     bool done = false;
     // APM_FORCE_RCCL=1 runs the collective even on one device (test hook for the RCCL path)
-    if ((G > 1 || getenv("APM_FORCE_RCCL")) && !getenv("APM_NO_RCCL")) {
+    bool distinct = true; // (APM_DEVICES rehearsal: shards sharing a GPU are summed on the host)
+    for (size_t a = 0; a < G; ++a)
+        for (size_t b = a + 1; b < G; ++b)
+            if (ctx->devs[a].dev == ctx->devs[b].dev) distinct = false;
+    if (distinct && (G > 1 || getenv("APM_FORCE_RCCL")) && !getenv("APM_NO_RCCL")) {
         if (load_rccl(ctx) == APM_OK) {
             // one ncclAllReduce(sum, uint64 x P) per device, grouped (RCCL over xGMI);
             // replaces the MPI_Send/Recv + manual sum of database_over_ranks.c:174-195
@@ -1669,6 +1683,11 @@ int init_device(apm_ctx *ctx, DeviceState &ds, int dev) {
 
 // the three host-level entry points share this: `stage(g, ds, lo, len)` must enqueue the
 // bytes of global positions [lo, lo+len) into ds.d_text on ds.stream.
+// Staging runs CONCURRENTLY, one host thread per device (the replacement of the reference's per-rank reads,
+// /root/reference/src/database_over_ranks.c:141-166: there every MPI rank read its own piece at the same time; round 2
+// staged device g's whole shard before touching device g + 1).  The scan launches follow from the calling thread as
+// each device's staging thread returns: they are microseconds of host time, and the plan's cached launch geometry is
+// not written from several threads.
 template <typename Stage>
 int count_sharded(apm_ctx *ctx, uint64_t n, uint64_t *counts, Stage stage) {
     if (!ctx) return APM_ERR_INVALID;
@@ -1682,38 +1701,118 @@ int count_sharded(apm_ctx *ctx, uint64_t n, uint64_t *counts, Stage stage) {
     const int G = (int)ctx->devs.size();
     const int P = (int)ctx->pats.size();
     const uint64_t halo = (uint64_t)std::max(ctx->m_max, 1) - 1;
-    for (int g = 0; g < G; ++g) {
+    struct Shard { uint64_t ob = 0, oe = 0, lo = 0, len = 0; int rc = APM_OK; };
+    std::vector<Shard> sh((size_t)G);
+    auto stage_device = [&](int g) {
         DeviceState &ds = ctx->devs[g];
-        uint64_t ob = 0, oe = 0;
-        apm_shard_range(n, ctx->k, g, G, &ob, &oe);
-        HIP_TRY(ctx, hipSetDevice(ds.dev));
-        HIP_TRY(ctx, hipEventRecord(ds.ev_start, ds.stream));
-        HIP_TRY(ctx, hipMemsetAsync(ds.d_counts, 0, std::max<size_t>((size_t)P * 8, 16), ds.stream));
-        const uint64_t lo = ob, hi = std::min<uint64_t>(n, oe + halo);
-        const uint64_t len = hi > lo ? hi - lo : 0;
-        if (oe > ob) {
-            int rc = ensure_text(ctx, ds, (size_t)len + 16);
-            if (rc) return rc;
-            rc = stage(g, ds, lo, len);
-            if (rc) return rc;
-        }
-        HIP_TRY(ctx, hipEventRecord(ds.ev_kstart, ds.stream));
-        if (oe > ob) {
-            int rc = scan_shard(ctx, ds, ds.d_text, lo, len, n, ob, oe, ds.d_counts);
-            if (rc) return rc;
-            account(ctx, n, ob, oe);
-        } else {
-            HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
-            HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
-        }
-        HIP_TRY(ctx, hipEventRecord(ds.ev_stop, ds.stream));
-        ds.events_recorded = true;
+        Shard &S = sh[(size_t)g];
+        apm_shard_range(n, ctx->k, g, G, &S.ob, &S.oe);
+        S.lo = S.ob;
+        const uint64_t hi = std::min<uint64_t>(n, S.oe + halo);
+        S.len = hi > S.lo ? hi - S.lo : 0;
+        S.rc = [&]() -> int {
+            HIP_TRY(ctx, hipSetDevice(ds.dev));
+            HIP_TRY(ctx, hipEventRecord(ds.ev_start, ds.stream));
+            HIP_TRY(ctx, hipMemsetAsync(ds.d_counts, 0, std::max<size_t>((size_t)P * 8, 16), ds.stream));
+            if (S.oe > S.ob) {
+                int rc = ensure_text(ctx, ds, (size_t)S.len + 16);
+                if (rc) return rc;
+                rc = stage(g, ds, S.lo, S.len);
+                if (rc) return rc;
+            }
+            HIP_TRY(ctx, hipEventRecord(ds.ev_kstart, ds.stream));
+            return APM_OK;
+        }();
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; ++g) th.emplace_back(stage_device, g);
+    stage_device(0);
+    int first_rc = APM_OK;
+    for (int g = 0; g < G; ++g) {
+        if (g > 0) th[(size_t)g - 1].join();
+        DeviceState &ds = ctx->devs[g];
+        const Shard &S = sh[(size_t)g];
+        if (S.rc && !first_rc) first_rc = S.rc;
+        if (first_rc) continue; // (keep joining)
+        int rc = [&]() -> int {
+            HIP_TRY(ctx, hipSetDevice(ds.dev));
+            if (S.oe > S.ob) {
+                const int r2 = scan_shard(ctx, ds, ds.d_text, S.lo, S.len, n, S.ob, S.oe, ds.d_counts);
+                if (r2) return r2;
+                account(ctx, n, S.ob, S.oe);
+            } else {
+                HIP_TRY(ctx, hipEventRecord(ds.ev_mstart, ds.stream));
+                HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
+            }
+            HIP_TRY(ctx, hipEventRecord(ds.ev_stop, ds.stream));
+            ds.events_recorded = true;
+            return APM_OK;
+        }();
+        if (rc && !first_rc) first_rc = rc;
     }
+    if (first_rc) return first_rc;
     int rc = reduce_counts(ctx, counts);
     if (rc) return rc;
     rc = collect_event_times(ctx);
     if (rc) return rc;
     ctx->timing.total_ms = ms_since(t0);
+    return APM_OK;
+}
+
+// Host bytes -> device text through the context's ring of pinned staging buffers (apm_count_buffer, apm_count_file).
+// `read(off, dst, len)` must put bytes [off, off+len) of the source into dst (false: I/O error).  Device g of G owns the
+// buffers [g * per, (g + 1) * per) of the ring, two per reader thread: a reader takes the next 8 MiB chunk of the
+// device's shard, reads it into one of its two buffers, enqueues the copy on the device's stream and reads the next
+// chunk into the other while that one travels (a buffer is reused once its copy's event has fired).  A single reader
+// runs at a fraction of the PCIe link; several side by side keep it busy (2 -> 35, 4 -> 44, 8 -> 40 GB/s on one
+// device), and no pages of the caller's buffer are pinned per call.
+int stage_through_ring(apm_ctx *ctx, int g, int G, DeviceState &ds, uint64_t lo, uint64_t len,
+                       const std::function<bool(uint64_t, uint8_t *, size_t)> &read) {
+    const size_t CH = apm_ctx::STAGE_BYTES;
+    static const int n_readers = [] {
+        const char *e = getenv("APM_INGEST_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        int t = e ? atoi(e) : std::min(4, hw > 1 ? hw / 2 : 1);
+        return t < 1 ? 1 : t;
+    }();
+    const int per = std::max(2, (apm_ctx::N_STAGE / std::max(G, 1)) & ~1); // buffers of this device (G <= N_STAGE / 2)
+    if ((g + 1) * per > apm_ctx::N_STAGE) return fail(ctx, APM_ERR_UNSUPPORTED, "more devices than staging buffers");
+    const int b0 = g * per;
+    const uint64_t n_chunks = (len + CH - 1) / CH;
+    const int nt = (int)std::min<uint64_t>((uint64_t)std::min(n_readers, per / 2), n_chunks);
+    for (int b = b0; b < b0 + 2 * nt; ++b) { // (current device = ds.dev; these buffers are this device's alone)
+        if (!ctx->stage[b] && hipHostMalloc((void **)&ctx->stage[b], CH, hipHostMallocDefault) != hipSuccess)
+            return fail(ctx, APM_ERR_NOMEM, "cannot allocate pinned staging buffers");
+        if (!ds.ev_stage[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ds.ev_stage[b], hipEventDisableTiming));
+    }
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> bad{0};
+    auto reader = [&](int t) {
+        if (hipSetDevice(ds.dev) != hipSuccess) { bad = 2; return; }
+        int flip = 0;
+        bool used[2] = {false, false};
+        for (;;) {
+            const uint64_t c = next.fetch_add(1);
+            if (c >= n_chunks || bad.load()) break;
+            const int b = b0 + 2 * t + flip;
+            if (used[flip] && hipEventSynchronize(ds.ev_stage[b]) != hipSuccess) { bad = 2; break; }
+            const uint64_t off = c * CH;
+            const size_t want = (size_t)std::min<uint64_t>(CH, len - off);
+            if (!read(lo + off, ctx->stage[b], want)) { bad = 1; break; }
+            if (hipMemcpyAsync(ds.d_text + off, ctx->stage[b], want, hipMemcpyHostToDevice, ds.stream) != hipSuccess ||
+                hipEventRecord(ds.ev_stage[b], ds.stream) != hipSuccess) { bad = 2; break; }
+            used[flip] = true;
+            flip ^= 1;
+        }
+        for (int f = 0; f < 2; ++f) // the buffers are free again when this call returns (the next call may be another device's)
+            if (used[f] && hipEventSynchronize(ds.ev_stage[b0 + 2 * t + f]) != hipSuccess) bad = 2;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(reader, t);
+    if (nt > 0) reader(0);
+    for (auto &t : th) t.join();
+    if (bad.load() == 1) return fail(ctx, APM_ERR_IO, "Unable to copy %llu byte(s) from text file", (unsigned long long)len);
+    if (bad.load()) return fail(ctx, APM_ERR_HIP, "staging copy failed: %s", hipGetErrorString(hipGetLastError()));
     return APM_OK;
 }
 
@@ -1762,9 +1861,28 @@ int apm_create(apm_ctx **ctx, int n_devices) {
     const int have = apm_device_count();
     if (have < 0) return have;
     if (have == 0) return fail(nullptr, APM_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    std::vector<int> devs;
+    // APM_DEVICES=a,b,...: the device ids of the context, in shard order, instead of 0 .. n_devices-1.  An id may repeat
+    // ("0,0"): several shards then share one GPU, each with its own stream, text buffer and count vector -- the rehearsal of
+    // the multi-device path on a one-GPU box (tests); the partial counts are then summed on the host (RCCL wants one rank
+    // per device).
+    if (const char *e = getenv("APM_DEVICES")) {
+        for (const char *p = e; *p;) {
+            char *end = nullptr;
+            const long id = strtol(p, &end, 10);
+            if (end == p || id < 0 || id >= have) return fail(nullptr, APM_ERR_NO_DEVICE, "APM_DEVICES: bad device list <%s> (%d visible)", e, have);
+            devs.push_back((int)id);
+            p = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') return fail(nullptr, APM_ERR_NO_DEVICE, "APM_DEVICES: bad device list <%s>", e);
+        }
+        if (devs.empty() || (int)devs.size() > apm_ctx::N_STAGE / 2) return fail(nullptr, APM_ERR_NO_DEVICE, "APM_DEVICES: bad device list <%s>", e);
+        if (n_devices > 0 && n_devices != (int)devs.size())
+            return fail(nullptr, APM_ERR_NO_DEVICE, "%d devices requested, APM_DEVICES lists %d", n_devices, (int)devs.size());
+        return create_common(ctx, devs, true);
+    }
     if (n_devices <= 0) n_devices = have;
     if (n_devices > have) return fail(nullptr, APM_ERR_NO_DEVICE, "%d devices requested, %d visible", n_devices, have);
-    std::vector<int> devs;
+    if (n_devices > apm_ctx::N_STAGE / 2) return fail(nullptr, APM_ERR_NO_DEVICE, "at most %d devices per context", apm_ctx::N_STAGE / 2);
     for (int i = 0; i < n_devices; ++i) devs.push_back(i);
     return create_common(ctx, devs, true);
 }
@@ -1908,17 +2026,18 @@ int apm_count_shard_device(apm_ctx *ctx, const void *d_text, uint64_t text_off, 
 int apm_count_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *counts) {
     if (!ctx) return APM_ERR_INVALID;
     if (!text && n) return fail(ctx, APM_ERR_INVALID, "text is NULL");
-    // pin the caller's buffer so the per-device copies are truly asynchronous
-    bool pinned = false;
-    if (n >= (1u << 20) && ctx->devs.size() > 0)
-        pinned = hipHostRegister((void *)text, (size_t)n, hipHostRegisterDefault) == hipSuccess;
-    if (!pinned) (void)hipGetLastError();
-    const int rc = count_sharded(ctx, n, counts, [&](int, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
-        HIP_TRY(ctx, hipMemcpyAsync(ds.d_text, text + lo, (size_t)len, hipMemcpyHostToDevice, ds.stream));
-        return APM_OK;
+    const int G = (int)ctx->devs.size();
+    return count_sharded(ctx, n, counts, [&](int g, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
+        if (len < (1u << 20)) { // small: one pageable copy (the runtime stages it itself)
+            HIP_TRY(ctx, hipMemcpyAsync(ds.d_text, text + lo, (size_t)len, hipMemcpyHostToDevice, ds.stream));
+            return APM_OK;
+        }
+        // through the pinned ring: round 2 pinned the caller's whole buffer with hipHostRegister on every call
+        return stage_through_ring(ctx, g, G, ds, lo, len, [&](uint64_t off, uint8_t *dst, size_t want) {
+            memcpy(dst, text + off, want);
+            return true;
+        });
     });
-    if (pinned) hipHostUnregister((void *)text);
-    return rc;
 }
 
 int apm_count_file(apm_ctx *ctx, const char *path, uint64_t *counts) {
@@ -1932,64 +2051,19 @@ int apm_count_file(apm_ctx *ctx, const char *path, uint64_t *counts) {
         return fail(ctx, APM_ERR_IO, "Unable to stat the text file <%s>", path);
     }
     const uint64_t n = (uint64_t)st.st_size;
-    // Chunked ingest: every reader thread owns two pinned staging buffers (kept for the life of the context) and takes
-    // the next 8 MiB chunk of the device's shard: pread out of the page cache, hipMemcpyAsync onto the device's stream,
-    // next chunk into its other buffer while that one travels.  A single pread stream runs at a fraction of the PCIe
-    // link; several of them side by side keep the link busy, and no thread is created or joined per chunk.
-    const size_t CH = apm_ctx::STAGE_BYTES;
-    static const int n_readers = [] {
-        const char *e = getenv("APM_INGEST_THREADS");
-        const int hw = (int)std::thread::hardware_concurrency();
-        int t = e ? atoi(e) : std::min(4, hw > 1 ? hw / 2 : 1); // (measured: 2 -> 35, 4 -> 44, 8 -> 40 GB/s)
-        return t < 1 ? 1 : (t > apm_ctx::N_STAGE / 2 ? apm_ctx::N_STAGE / 2 : t);
-    }();
-    DeviceState *owner[apm_ctx::N_STAGE] = {}; // device whose copy out of buffer b is pending
-    int rc = count_sharded(ctx, n, counts, [&](int, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
-        const uint64_t n_chunks = (len + CH - 1) / CH;
-        const int nt = (int)std::min<uint64_t>((uint64_t)n_readers, n_chunks);
-        for (int b = 0; b < 2 * nt; ++b) { // (current device = ds.dev)
-            if (!ctx->stage[b] && hipHostMalloc((void **)&ctx->stage[b], CH, hipHostMallocDefault) != hipSuccess)
-                return fail(ctx, APM_ERR_NOMEM, "cannot allocate pinned staging buffers");
-            if (owner[b] && owner[b] != &ds) { // an earlier device's copy out of this buffer
-                HIP_TRY(ctx, hipEventSynchronize(owner[b]->ev_stage[b]));
-                owner[b] = nullptr;
+    const int G = (int)ctx->devs.size();
+    // chunked ingest, all devices at once (stage_through_ring): pread out of the page cache into pinned buffers
+    const int rc = count_sharded(ctx, n, counts, [&](int g, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
+        return stage_through_ring(ctx, g, G, ds, lo, len, [&](uint64_t off, uint8_t *dst, size_t want) {
+            size_t got = 0;
+            while (got < want) {
+                const ssize_t r = pread(fd, dst + got, want - got, (off_t)(off + got));
+                if (r <= 0) return false;
+                got += (size_t)r;
             }
-            if (!ds.ev_stage[b]) HIP_TRY(ctx, hipEventCreateWithFlags(&ds.ev_stage[b], hipEventDisableTiming));
-        }
-        std::atomic<uint64_t> next{0};
-        std::atomic<int> bad{0};
-        auto reader = [&](int t) {
-            if (hipSetDevice(ds.dev) != hipSuccess) { bad = 2; return; }
-            int flip = 0;
-            for (;;) {
-                const uint64_t c = next.fetch_add(1);
-                if (c >= n_chunks || bad.load()) return;
-                const int b = 2 * t + flip;
-                flip ^= 1;
-                if (owner[b] && hipEventSynchronize(ds.ev_stage[b]) != hipSuccess) { bad = 2; return; }
-                const uint64_t off = c * CH;
-                const size_t want = (size_t)std::min<uint64_t>(CH, len - off);
-                size_t got = 0;
-                while (got < want) {
-                    const ssize_t r = pread(fd, ctx->stage[b] + got, want - got, (off_t)(lo + off + got));
-                    if (r <= 0) { bad = 1; return; }
-                    got += (size_t)r;
-                }
-                if (hipMemcpyAsync(ds.d_text + off, ctx->stage[b], want, hipMemcpyHostToDevice, ds.stream) != hipSuccess ||
-                    hipEventRecord(ds.ev_stage[b], ds.stream) != hipSuccess) { bad = 2; return; }
-                owner[b] = &ds; // (buffer b belongs to thread t alone)
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(reader, t);
-        reader(0);
-        for (auto &t : th) t.join();
-        if (bad.load() == 1) return fail(ctx, APM_ERR_IO, "Unable to copy %llu byte(s) from text file", (unsigned long long)len);
-        if (bad.load()) return fail(ctx, APM_ERR_HIP, "staging copy failed: %s", hipGetErrorString(hipGetLastError()));
-        return APM_OK;
+            return true;
+        });
     });
-    for (int b = 0; b < apm_ctx::N_STAGE; ++b)
-        if (owner[b]) hipEventSynchronize(owner[b]->ev_stage[b]);
     close(fd);
     return rc;
 }

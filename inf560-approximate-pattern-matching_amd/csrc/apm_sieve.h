@@ -76,11 +76,14 @@ struct ApmVerifyArgs {
     const uint4 *image;
     int image_len, o_prefix, o_r2s, o_slots, o_kext, o_pat;
     int o_masks;                /* 17 x 16 bytes: entry n = n leading 0xff bytes (byte masks of a compare of n <= 16 bytes) */
-    /* the records only the (rare) banded DP needs stay in global memory */
-    const uint32_t *kinfo;      /* per key = nomination unit: pat | off << 12 | unit index inside the pattern << 21; off = offset of
-                                   the unit's text position inside the window (window start = position - off - shift) */
-    const uint2 *pinfo;         /* per pattern: {byte_off | m << 16, id of its first key}; a pattern's units are consecutive keys */
-    const uint32_t *kpart;      /* per key: partner offset inside the pattern | partner length << 16 (partners beyond 16 bytes only) */
+    int o_kinfo, o_pinfo;       /* the records of the banded DP and the dedup, in the image too (round 2 kept them in global memory:
+                                   with the sieve's code filter in front the DP is most of the launch, and kinfo -> pinfo -> text
+                                   was a chain of three memory round trips per DP batch) */
+    const uint32_t *kinfo;      /* (global copy, unused by the kernels) per key = nomination unit: pat | off << 12 | unit index inside
+                                   the pattern << 21; off = offset of the unit's text position inside the window (window start =
+                                   position - off - shift) */
+    const uint2 *pinfo;         /* (global copy) per pattern: {byte_off | m << 16, id of its first key}; a pattern's units are consecutive keys */
+    const uint32_t *kpart;      /* global, per key: partner offset inside the pattern | partner length << 16 (partners beyond 16 bytes only) */
     const ApmPatDesc *pats;     /* index = counts[] slot */
     unsigned long long *counts;
     int n_pats, nk, k, band, code_shift;

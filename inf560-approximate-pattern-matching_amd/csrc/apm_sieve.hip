@@ -30,7 +30,12 @@
 #define APM_WORK_CH8 8u /* ... sampled sets (8, 16: the same) */
 #endif
 #ifndef APM_FUSED_NBLK
-#define APM_FUSED_NBLK 2u /* fused sampled form: blocks per sieve step (2 beats 1 by 4 %, 4 spills) */
+#define APM_FUSED_NBLK 2u /* fused sampled form without prefetch: blocks per sieve step (2 beats 1 by 4 %, 4 spills) */
+#endif
+#ifndef APM_FUSED_PREFETCH
+#define APM_FUSED_PREFETCH 1 /* fused sampled form: one block per step, the NEXT block's 4 KiB in flight while this one is sieved
+                                and its hits verified -- the access shape of the plain sieve kernels (tools/stream_probe.hip: 4 KiB
+                                per wave and round streams at 6.2 TB/s, 8 KiB at 4.4) */
 #endif
 #ifndef APM_VERIFY_PIPE
 #define APM_VERIFY_PIPE 2 /* batches formed ahead of the one in hand (2 beats 1 by 17 % on cfg3: the window loads of batch b+1 then do not wait for the queue reads that form it) */
@@ -418,6 +423,8 @@ struct ApmVerifyCore {
     const uint8_t *s_pat;
     uint32_t *s_cnt;
     int lane;
+    const uint32_t *s_kinfo; // per key (LDS: the DP and the dedup are a chain of dependent reads, and with the sieve's code
+    const uint2 *s_pinfo;    // filter in front they are most of what the launch does); per pattern
 
     __device__ __forceinline__ void load_global(uint32_t a0, ApmWin &o) const {
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)a0, 0, 0);
@@ -450,7 +457,7 @@ struct ApmVerifyCore {
         if (!PAIRS || side == 0) return true; // no pre-check (k <= 1) / unpaired last piece (even k)
         if (n == 31) { // partner longer than 16 bytes: byte loops (definition of the core, apm_ext_fwd / apm_ext_bwd)
             const uint32_t kp = a.kpart[kid];
-            const int poff = (int)(a.pinfo[a.kinfo[kid] & 0xfffu].x & 0xffffu), ap = (int)(kp & 0xffffu), nn = (int)(kp >> 16), ap1 = ap + nn;
+            const int poff = (int)(s_pinfo[s_kinfo[kid] & 0xfffu].x & 0xffffu), ap = (int)(kp & 0xffffu), nn = (int)(kp >> 16), ap1 = ap + nn;
             const bool fwd = side == 1;
             auto T = [&](int i) { return fwd ? gbyte(s + (uint32_t)len + (uint32_t)i) : gbyte(s - 1u - (uint32_t)i); };      // text, read away from the exact part
             auto P = [&](int i) { return fwd ? (int)s_pat[poff + ap + i] : (int)s_pat[poff + ap1 - 1 - i]; };                // partner, same direction
@@ -519,9 +526,9 @@ struct ApmVerifyCore {
     // ---- banded DP of the window a nomination (unit kid at text position s) implies under shift dl ----
     // on a match: wpat = pattern slot, wj = window start, word = rank of (unit, shift) among the window's nominators
     __device__ __forceinline__ bool dp_match(uint32_t kid, uint32_t s, int dl, uint32_t &wpat, uint32_t &wj, uint32_t &word) const {
-        const uint32_t ki = a.kinfo[kid];
+        const uint32_t ki = s_kinfo[kid];
         const int kpat = (int)(ki & 0xfffu), koff = (int)((ki >> 12) & 0x1ffu), kunit = (int)((ki >> 21) & 7u);
-        const uint2 pinf = a.pinfo[kpat];
+        const uint2 pinf = s_pinfo[kpat];
         const int poff = (int)(pinf.x & 0xffffu), m = (int)(pinf.x >> 16);
         const int64_t je_p = min(a.je, a.nrel - m + 1);
         const int64_t j = (int64_t)s - koff - dl; // candidate window start
@@ -553,14 +560,14 @@ struct ApmVerifyCore {
             hm &= hm - 1ull;
             const uint32_t bpat = (uint32_t)__builtin_amdgcn_readlane((int)wpat, src), bj = (uint32_t)__builtin_amdgcn_readlane((int)wj, src);
             const int n_before = __builtin_amdgcn_readlane((int)word, src); // (unit, shift) pairs in front of this one: < 64
-            const uint32_t kid0 = a.pinfo[bpat].y; // the pattern's first unit
+            const uint32_t kid0 = s_pinfo[bpat].y; // the pattern's first unit
             bool earlier = false;
 #ifdef APM_MEASURE
             if (APM_SKIP(a, 32)) continue;
 #endif
             if (lane < n_before) {
                 const int qq = lane / NSH, dd = lane % NSH - BAND;
-                const int64_t o = (int64_t)bj + (int)((a.kinfo[kid0 + (uint32_t)qq] >> 12) & 0x1ffu) + dd; // the unit's text position under shift dd
+                const int64_t o = (int64_t)bj + (int)((s_kinfo[kid0 + (uint32_t)qq] >> 12) & 0x1ffu) + dd; // the unit's text position under shift dd
                 if (o >= 0) {
                     ApmWin w2;
                     load_global((uint32_t)o & ~3u, w2);
@@ -619,7 +626,8 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     const uint32_t avail = (uint32_t)a.avail;
     const uint32_t cs = (uint32_t)a.code_shift;
 
-    ApmVerifyCore<BAND> core{a, rs, avail, s_kext, s_masks, s_pat, s_cnt, lane};
+    ApmVerifyCore<BAND> core{a, rs, avail, s_kext, s_masks, s_pat, s_cnt, lane, reinterpret_cast<const uint32_t *>(s_img + a.o_kinfo),
+                             reinterpret_cast<const uint2 *>(s_img + a.o_pinfo)};
     typedef ApmWin Win;
     auto load_win = [&](uint32_t a0, Win &o) __attribute__((always_inline)) { core.load_global(a0, o); };
 
@@ -638,12 +646,14 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     // atomics per microsecond chip-wide); wave w belongs to group w % APM_WORK_GROUPS -- every group is a sample of the
     // whole machine, so the groups finish together -- and takes the group's next chunk with one atomic, issued a
     // chunk ahead of its use.  The counters of the NEXT launch are zeroed here (two sets, the host alternates). ----
-    constexpr uint32_t CH = SAMPLED ? APM_WORK_CH8 : APM_WORK_CH;
     // 4 KiB blocks in all; with a block list (ApmVerifyArgs::blist) only the listed ones: entry b of the list is the block
     // -- when the list is short: with most blocks on it (cfg3) the walk over all rows is the shorter chain of loads
     const uint32_t n_listed = (!FUSED && a.blist != nullptr) ? *a.blist_ctr : 0xffffffffu;
     const bool listed = n_listed < (uint32_t)a.n_mask_blocks / 4u;
     const uint32_t NB = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : (listed ? n_listed : (uint32_t)a.n_mask_blocks);
+    // blocks per chunk: a short list is dealt block by block (cfg5: 10 K listed blocks for 4 K waves -- with chunks of 8 most
+    // waves got none and the rest walked theirs one load after the other: 0.072 ms against 0.036)
+    const uint32_t CH = SAMPLED ? APM_WORK_CH8 : (listed ? 1u : APM_WORK_CH);
     const uint32_t NC = (NB + CH - 1u) / CH;
     // NG = min(APM_WORK_GROUPS, waves of the launch): no group without a wave.  Workgroups go round the XCDs, so the low
     // bits of the wave number alone would tie a group to one XCD and one wave slot: fold the higher bits in
@@ -657,7 +667,21 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     uint32_t grab_v = grab();
     uint32_t it_b = 0, it_end = 0; // the chunk in hand: blocks [it_b, it_end)
     bool it_done = false;
+#ifndef APM_FUSED_STATIC
+#define APM_FUSED_STATIC 1 /* fused sampled form: blocks dealt statically, wave w takes blocks w, w + W, ... -- with the register
+                              compare in front next to nothing is left to verify, so there is nothing to balance, and the
+                              waves of a round read one contiguous stretch of text (the plain sieve's access shape) */
+#endif
+    constexpr bool STATIC_BLOCKS = FUSED && SAMPLED && APM_FUSED_STATIC;
+    const uint32_t n_waves_all = (uint32_t)(FUSED ? sv->n_main_blocks : (int)gridDim.x) * (uint32_t)(THREADS / 64); // (the scanning workgroups: not the tail ones)
+    uint32_t st_b = my_wave;
     auto it_next = [&](uint32_t &b) __attribute__((always_inline)) -> bool { // wave-uniform: the wave's next block
+        if constexpr (STATIC_BLOCKS) {
+            if (st_b >= NB) return false;
+            b = st_b;
+            st_b += n_waves_all;
+            return true;
+        }
         if (it_b >= it_end) {
             if (it_done) return false;
             const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)grab_v);
@@ -695,21 +719,83 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     // hit mask of this lane for the block at relative position b0 (see ApmSieve2Args::masks for the bit layout)
     // FUSED + SAMPLED: a sieve step takes NBLK neighbouring blocks (a block fills 8 of the 32 mask bits: block i of the step
     // sits in bits 8 j + 2 i + t) -- twice the bytes in flight per wave; the pass is bound by the latency of these loads
-    constexpr uint32_t NBLK = (FUSED && SAMPLED) ? APM_FUSED_NBLK : 1u;
+    constexpr bool PREF = FUSED && SAMPLED && APM_FUSED_PREFETCH;
+    constexpr uint32_t NBLK = (FUSED && SAMPLED && !PREF) ? APM_FUSED_NBLK : 1u;
+    u32x4 pf_r[4];      // PREF: the prefetched block's text
+    uint32_t pf_sl[4];  // ... the codes of the block in hand (packed before the next block's loads go out: no second copy of the text)
+    uint32_t pf_b = 0xffffffffu; // the prefetched block (none)
+    bool pf_started = false;
+    auto pf_issue = [&](uint32_t b) __attribute__((always_inline)) {
+        const uint32_t g = tile0 + b * 4096u + 16u * (uint32_t)lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pf_r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g + 1024u * j), 0, 0); // (beyond the text: zeros)
+    };
     auto sieve_block = [&](uint32_t b0, uint32_t fb, uint32_t nblk) __attribute__((always_inline)) -> uint32_t {
         const uint32_t g = b0 + 16u * (uint32_t)lane, c0 = fb * 4u;
         uint32_t out = 0;
         if constexpr (SAMPLED) { // one lookup per 8 bytes in the image's bitmap over 16-bit code words (apm_sieve8_kernel)
-            u32x4 r[4 * NBLK];
+            uint32_t sl[4 * NBLK]; // codes of the lane's 16 bytes, chunk by chunk
+            if constexpr (PREF) {
 #pragma unroll
-            for (int j = 0; j < (int)(4 * NBLK); ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g + 1024u * j), 0, 0); // (beyond the text: zeros)
+                for (int j = 0; j < 4; ++j) sl[j] = pf_sl[j];
+            } else {
+                u32x4 r[4 * NBLK];
+#pragma unroll
+                for (int j = 0; j < (int)(4 * NBLK); ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g + 1024u * j), 0, 0); // (beyond the text: zeros)
+#pragma unroll
+                for (int j = 0; j < (int)(4 * NBLK); ++j) sl[j] = pack4(r[j].x) | (pack4(r[j].y) << 8) | (pack4(r[j].z) << 16) | (pack4(r[j].w) << 24);
+            }
 #pragma unroll
             for (int j = 0; j < (int)(4 * NBLK); ++j) {
-                const uint32_t slo = pack4(r[j].x) | (pack4(r[j].y) << 8) | (pack4(r[j].z) << 16) | (pack4(r[j].w) << 24);
+                const uint32_t slo = sl[j];
                 const uint32_t w0 = s_bmp[slo & 2047u], w1 = s_bmp[(slo >> 16) & 2047u];
                 const uint32_t h = ((w0 >> ((slo >> 11) & 31u)) & 1u) | (((w1 >> (slo >> 27)) & 1u) << 1);
                 out |= ((c0 + j < nch32 && (uint32_t)(j >> 2) < nblk) ? h : 0u) << (8 * (j & 3) + 2 * (j >> 2));
             }
+            // REGISTER COMPARE: a hit says "an 8-byte block of some key's piece, r bytes into the piece, may lie here"; the
+            // piece is >= 15 bytes long, so more of it lies inside the lane's own 16 bytes -- compare the codes of that overlap
+            // (pattern bytes out of the LDS image, packed like the text) before the hit is queued.  What was queued before
+            // -- 0.8 M hits per GiB for cfg4, practically all false, each with two window gathers that missed the caches
+            // (1.18 x the text in HBM traffic) -- no longer leaves the lane.  A filter (codes equal is necessary for the
+            // piece to be intact at position - r, stage1's first test); lanes work on their own hits, one key at a time.
+#ifndef APM_NO_REGCMP /* (A/B builds: tools/build_variant.sh) */
+            {
+                uint32_t pend = out, cur = 0, curbit = 0, slo_c = 0, tsel = 0;
+                bool act = false;
+                for (;;) {
+                    if (!act && pend) { // the lane's next hit: key list of its code word by rank
+                        curbit = (uint32_t)__builtin_ctz(pend);
+                        pend &= pend - 1u;
+                        tsel = curbit & 1u;
+                        const uint32_t j = (curbit >> 3) + 4u * ((curbit >> 1) & 3u);
+#pragma unroll
+                        for (int q = 0; q < (int)(4 * NBLK); ++q)
+                            if (j == (uint32_t)q) slo_c = sl[q];
+                        const uint32_t x = tsel ? (slo_c >> 16) : (slo_c & 0xffffu), bit = x >> 11;
+                        const uint32_t word = s_bmp[x & 2047u];
+                        const uint32_t e = s_r2s[(uint32_t)s_prefix[x & 2047u] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))];
+                        cur = (e & 0x8000u) ? e : ((uint32_t)s_slots[e] | ((e + 1u) << 16));
+                        act = true;
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(act)) break;
+                    if (act) {
+                        const uint32_t kid = cur & 2047u, rr = (cur & 0x7fffu) >> 11; // (KBITS = 11: key id | offset of the block in its piece)
+                        const uint32_t kx = s_kext[kid];
+                        const int at = (int)(kx & 0xffffu), len = (int)((kx >> 16) & 0xffu);
+                        // lane byte i <-> piece byte i - 8 t + r <-> pattern pool byte at + r - 8 t + i
+                        const int sh8 = (int)(8u * tsel) - (int)rr;
+                        uint32_t B[4];
+                        apm_lds_dwords<4>(s_pat, at - sh8, B);
+                        const uint32_t pc = pack4(B[0]) | (pack4(B[1]) << 8) | (pack4(B[2]) << 16) | (pack4(B[3]) << 24);
+                        const int i0 = sh8 > 0 ? sh8 : 0, i1 = len + sh8 < 16 ? len + sh8 : 16; // the piece covers lane bytes [i0, i1)
+                        const uint32_t mhi = i1 >= 16 ? 0xffffffffu : ((1u << (2 * i1)) - 1u), mlo = (1u << (2 * i0)) - 1u;
+                        if ((((pc ^ slo_c) & mhi) & ~mlo) == 0u) act = false; // may be intact: the hit stays
+                        else if (cur & 0x8000u) { act = false; out &= ~(1u << curbit); } // no key of the word fits
+                        else cur = (uint32_t)s_slots[cur >> 16] | ((cur & 0xffff0000u) + 0x10000u);
+                    }
+                }
+            }
+#endif
         } else { // one lookup per even position in the 32 KiB bitmap over 18-bit code words at LDS address 0 (apm_sieve2_kernel)
             // (chunks behind the scanned range are loaded all the same -- text or zeros -- since the windows of the last
             // valid chunk run into them; only their own hits are dropped)
@@ -746,7 +832,20 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
             if (!__builtin_amdgcn_ballot_w64(hm != 0u)) { // block done: take the prefetched masks of the next one
                 if constexpr (FUSED) { // ... or sieve the wave's next block
                     uint32_t b;
-                    if (!it_next(b)) break;
+                    if constexpr (PREF) {
+                        if (!pf_started) {
+                            pf_started = true;
+                            uint32_t nb;
+                            if (it_next(nb)) { pf_b = nb; pf_issue(nb); }
+                        }
+                        if (pf_b == 0xffffffffu) break;
+                        b = pf_b;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pf_sl[j] = pack4(pf_r[j].x) | (pack4(pf_r[j].y) << 8) | (pack4(pf_r[j].z) << 16) | (pack4(pf_r[j].w) << 24);
+                        uint32_t nb;
+                        if (it_next(nb)) { pf_b = nb; pf_issue(nb); }
+                        else pf_b = 0xffffffffu;
+                    } else if (!it_next(b)) break;
                     blk = tile0 + b * 4096u;
                     uint32_t nblk = 1; // the step's blocks: neighbours out of the same chunk
                     for (; nblk < NBLK && it_b < it_end; ++nblk) ++it_b;
@@ -977,7 +1076,7 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
 // FUSED: sieve + verify in one launch (apm_verify_body<.., FUSED = true>; see ApmFusedArgs)
 // ---------------------------------------------------------------------------
 template <int BAND, bool SAMPLED>
-__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND <= 1 ? 7 : (BAND == 2 ? 6 : 5)) : (BAND <= 1 ? 6 : 5)) void apm_fused_kernel(ApmFusedArgs f) {
+__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND == 0 ? 7 : 5) : (BAND <= 1 ? 6 : 5)) void apm_fused_kernel(ApmFusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if ((int)blockIdx.x >= f.s.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
         apm_tail_body(f.s.tail, (int)blockIdx.x - f.s.n_main_blocks, reinterpret_cast<uint4 *>(smem), (int)threadIdx.x);

@@ -708,6 +708,49 @@ def test_rccl_allreduce_path_single_device(apm):
     assert r.stdout.decode().strip().splitlines()[-1] == str(c["counts"])
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_multi_device_context_rehearsed_on_one_gpu(apm, tmp_path, devices):
+    """The single-process multi-device path (apm_create(G): one DeviceState per shard -- own stream, text buffer, plan copy
+    and count vector --, concurrent staging threads, partial counts summed at the end) rehearsed on this one GPU:
+    APM_DEVICES=0,0 makes a context of two (three) shards that share device 0.  Counts must equal the single-device
+    counts for the reference's data files (host buffer and file ingest), for a 64 MiB cfg3 text through the pinned staging
+    ring, and for the device-side generator."""
+    os.environ["APM_DEVICES"] = devices
+    try:
+        multi = apm.ApmContext(n_devices=0)
+    finally:
+        del os.environ["APM_DEVICES"]
+    G = len(devices.split(","))
+    try:
+        assert multi.timing()["n_devices"] in (0, G)
+        for name in ("x100_k2", "chrY_k3"):
+            c = next(c for c in CASES if c["name"] == name)
+            text = H.case_text(c)
+            multi.set_patterns(c["patterns"], c["k"])
+            assert multi.count_buffer(text) == c["counts"], (name, devices)
+            assert multi.timing()["n_devices"] == G
+            f = tmp_path / (name + ".txt")
+            f.write_bytes(text)
+            assert multi.count_file(str(f)) == c["counts"], (name, devices)
+        wl = H.workloads()
+        cfg = wl.CONFIGS["cfg3"]
+        n, k, seed = 64 << 20, cfg["k"], wl.seed_of(cfg["cid"])
+        pats, planted = wl.make_patterns(n, cfg["lens"], k, seed)
+        text = apm.synth_fill_host(0, n, seed)
+        with apm.ApmContext(device=0) as one:
+            one.set_patterns(pats, k)
+            want = one.count_buffer(text)
+        multi.set_patterns(pats, k)
+        assert multi.count_buffer(text) == want
+        assert multi.count_synthetic(n, seed) == want
+        f = tmp_path / "cfg3_64m.txt"
+        f.write_bytes(text)
+        assert multi.count_file(str(f)) == want
+        assert sum(want) > 0 and all(cc >= 1 for cc, (o, d) in zip(want, planted) if d <= k)
+    finally:
+        multi.close()
+
+
 def test_bench_two_ranks_equal_one_rank():
     """bench.py's N > 1 path (owner-computes shards + halo + all-reduce of the partial counts), rehearsed with two
     ranks sharing this one GPU over gloo (RCCL refuses two ranks on one device): the summed counts must equal the
