@@ -59,12 +59,14 @@ typedef enum apm_status {
  * in how many DP cells they really evaluate.
  *   WAVEFRONT  full m x m DP, lanes own pattern rows, anti-diagonal sweep with
  *              DPP/__shfl column passing (the kernel BASELINE.json names)
- *   BITPAR     full m x m DP, one window per lane, Myers/Hyyro bit-vector
- *              columns (32 DP cells per integer op, up to 16 words: m <= 512),
- *              exact distance
+ *   BITPAR     full m x m DP, Myers/Hyyro bit-vector columns (32 DP cells per
+ *              integer op), exact distance: one window per lane with columns of
+ *              up to 32 words (m <= 1024), one window per wavefront beyond
+ *              (m <= 4096; the pattern's distinct bytes x 64 or 128 words of Eq
+ *              rows must fit 60 KiB of LDS, else GENERIC)
  *   BANDED     exact for the predicate dist<=k: only diagonals |x-y|<=k/2,
  *              early exit, candidates pre-filtered by pigeonhole sub-keys looked up
- *              in an LDS hash table (needs m<=256, k<=7, m/(k+1)>=4)
+ *              in LDS tables (needs m<=512, k<=7, m/(k+1)>=4)
  *   GENERIC    literal one-column DP per lane, any m, handles truncated tails
  *   AUTO       fastest applicable exact variant per pattern (default)        */
 typedef enum apm_kernel {

@@ -215,12 +215,15 @@ struct ApmUnit {
 /* the unit's code-filter record (apm_cf_pass) */
 inline void apm_cf_record(const uint8_t *pat, const ApmUnit &u, int shift, uint32_t *rx, uint32_t *ry) {
     auto code = [&](int y) { return (uint32_t)((pat[y] >> shift) & 3); };
-    const int np = u.side ? (u.plen < 15 ? u.plen : 15) : 0;
+    /* (an exact part beyond 255 bytes -- patterns beyond 256 bytes with k = 0 -- does not fit the record's length field:
+       the partner, whose position it gives, is then not judged) */
+    const int side = u.len > 255 ? 0 : u.side;
+    const int np = side ? (u.plen < 15 ? u.plen : 15) : 0;
     uint32_t p = 0, e2 = 0;
-    for (int i = 0; i < np; ++i) p |= code(u.side == 1 ? u.poff + i : u.poff + u.plen - 1 - i) << (2 * i);
+    for (int i = 0; i < np; ++i) p |= code(side == 1 ? u.poff + i : u.poff + u.plen - 1 - i) << (2 * i);
     for (int i = 8; i < u.len && i < 16; ++i) e2 |= code(u.off + i) << (2 * (i - 8));
-    *rx = p | ((uint32_t)u.side << 30);
-    *ry = e2 | ((uint32_t)np << 16) | ((uint32_t)u.len << 20);
+    *rx = p | ((uint32_t)side << 30);
+    *ry = e2 | ((uint32_t)np << 16) | ((uint32_t)(u.len < 255 ? u.len : 255) << 20);
 }
 
 /* can the text codes t[0..vis) (the first vis text bytes behind the exact part) still belong to a text that matches

@@ -10,10 +10,10 @@
 
 #define APM_BLOCK 256          /* threads per workgroup: 4 wave64 */
 #define APM_TILE_SLACK 320     /* bytes readable past tile+halo in LDS (ramp-down reads, 16B rounding) */
-#define APM_BITPAR_MAX_M 512
+#define APM_BITPAR_MAX_M 4096    /* <= 512: one window per lane, columns of <= 16 words (apm_bitpar.h); <= 1024: 24 / 32 words; <= 4096: one window per wave (apm_bitlong.hip) */
 #define APM_WAVEFRONT_MAX_M 256
 #define APM_LDS_TABLE_BUDGET (40 * 1024)
-#define APM_BANDED_MAX_M 256
+#define APM_BANDED_MAX_M 512     /* (unit offsets inside the pattern: 9 bits of the key records) */
 #define APM_BANDED_MIN_PIECE 4
 #define APM_BANDED_MAX_K 7
 #define APM_BANDED_MAX_PATS 64
@@ -160,6 +160,10 @@ hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s);
 hipError_t apm_launch_synth(uint8_t *dst, uint64_t global_off, uint64_t len, uint64_t seed, hipStream_t s);
 size_t apm_bitpar_lds_bytes(const ApmScanArgs &a);
+/* apm_bitlong.hip */
+hipError_t apm_launch_bitpar_xwide(const ApmScanArgs &a, unsigned n_tiles, size_t lds_bytes, hipStream_t s); /* 512 < m <= 1024 */
+hipError_t apm_launch_bitlong(const ApmScanArgs &a, int m, hipStream_t s);                                    /* 1024 < m <= 4096, one pattern */
+hipError_t apm_launch_tail_xwide(const ApmTailArgs &a, int n_pats, hipStream_t s);                            /* tails, 512 < m <= 1024 */
 size_t apm_wavefront_lds_bytes(const ApmScanArgs &a);
 
 #endif

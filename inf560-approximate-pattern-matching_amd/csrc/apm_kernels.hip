@@ -49,6 +49,7 @@ hipError_t apm_launch_bitpar(const ApmScanArgs &a, hipStream_t s) {
     if (span <= 0 || a.n_pats <= 0) return hipSuccess;
     const int64_t nt = (span + a.tile - 1) / a.tile;
     if (nt > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.halo >= 512) return apm_launch_bitpar_xwide(a, (unsigned)nt, apm_bitpar_lds_bytes(a), s); // 513 .. 1024 bytes (apm_bitlong.hip)
     if (a.halo >= 128) return apm_launch_bitpar_wide(a, (unsigned)nt, apm_bitpar_lds_bytes(a), s); // (the runtime never mixes; apm_bitpar_wide.hip)
     hipLaunchKernelGGL(apm_bitpar_kernel<false>, dim3((unsigned)nt), dim3(APM_BLOCK), apm_bitpar_lds_bytes(a), s, a);
     return hipGetLastError();

@@ -155,6 +155,7 @@ struct DeviceState {
     ApmPatDesc *d_tail_descs = nullptr;       // tails of tiled-kernel patterns with m > 128 (generic kernel)
     ApmPatDesc *d_stail_descs = nullptr;      // tails of tiled-kernel patterns with m <= 128 (tail kernel)
     ApmPatDesc *d_wtail_descs = nullptr;      // ... with 128 < m <= 512 (wide tail kernel)
+    ApmPatDesc *d_xtail_descs = nullptr;      // ... with 512 < m <= 1024 (32-word tail kernel)
     ApmPatDesc *d_long_descs = nullptr;       // generic full-scan patterns
     int *d_trivial = nullptr;                 // indices of the patterns with k >= m
     std::vector<DevTiled> tiled;
@@ -213,7 +214,8 @@ struct apm_ctx {
     SievePlan sieve;
     GenericGroup tails;   // tiled-kernel patterns with m > 128: tails by the generic kernel
     GenericGroup stails;  // tiled-kernel patterns with m <= 128: tails by the bit-vector tail kernel
-    GenericGroup wtails;  // ... with 128 < m <= 512: by its 16-word form (tails: beyond 512 only)
+    GenericGroup wtails;  // ... with 128 < m <= 512: by its 16-word form
+    GenericGroup xtails;  // ... with 512 < m <= 1024: by its 32-word form (apm_bitlong.hip)
     GenericGroup longs;   // patterns scanned fully by the generic kernel
     std::vector<int> trivial; // indices with k >= m
     std::vector<uint8_t> allpat;
@@ -288,8 +290,8 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
     if (forced == APM_KERNEL_AUTO) {
         if (k >= m) return KERNEL_TRIVIAL;
         if (m <= APM_BANDED_MAX_M && k <= APM_BANDED_MAX_K && m / (k + 1) >= APM_BANDED_MIN_PIECE) return APM_KERNEL_BANDED;
-        if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR; // short or loose (BANDED's pigeonhole pieces too short): bit-vector columns of up to 16 words
-        return APM_KERNEL_GENERIC;                           // m > 512 only
+        if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR; // short or loose (BANDED's pigeonhole pieces too short), or long: bit-vector columns
+        return APM_KERNEL_GENERIC;                           // m > 4096 only (and long patterns over big alphabets: build_plan)
     }
     switch (forced) {
     case APM_KERNEL_GENERIC: return APM_KERNEL_GENERIC;
@@ -297,11 +299,11 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
         if (m > APM_WAVEFRONT_MAX_M) { *why = "WAVEFRONT kernel supports pattern length <= 256"; return -100; }
         return APM_KERNEL_WAVEFRONT;
     case APM_KERNEL_BITPAR:
-        if (m > APM_BITPAR_MAX_M) { *why = "BITPAR kernel supports pattern length <= 512"; return -100; }
+        if (m > APM_BITPAR_MAX_M) { *why = "BITPAR kernel supports pattern length <= 4096"; return -100; }
         return APM_KERNEL_BITPAR;
     case APM_KERNEL_BANDED:
         if (m > APM_BANDED_MAX_M || k > APM_BANDED_MAX_K || m / (k + 1) < APM_BANDED_MIN_PIECE) {
-            *why = "BANDED kernel needs m <= 256, k <= 7 and m/(k+1) >= 4 (pigeonhole keys of >= 4 bytes)";
+            *why = "BANDED kernel needs m <= 512, k <= 7 and m/(k+1) >= 4 (pigeonhole keys of >= 4 bytes)";
             return -100;
         }
         return APM_KERNEL_BANDED;
@@ -323,6 +325,7 @@ void free_device_plan(DeviceState &ds) {
     if (ds.d_tail_descs) hipFree(ds.d_tail_descs), ds.d_tail_descs = nullptr;
     if (ds.d_stail_descs) hipFree(ds.d_stail_descs), ds.d_stail_descs = nullptr;
     if (ds.d_wtail_descs) hipFree(ds.d_wtail_descs), ds.d_wtail_descs = nullptr;
+    if (ds.d_xtail_descs) hipFree(ds.d_xtail_descs), ds.d_xtail_descs = nullptr;
     if (ds.d_long_descs) hipFree(ds.d_long_descs), ds.d_long_descs = nullptr;
     if (ds.d_trivial) hipFree(ds.d_trivial), ds.d_trivial = nullptr;
     if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
@@ -636,6 +639,7 @@ int build_plan(apm_ctx *ctx) {
     ctx->tails = GenericGroup();
     ctx->stails = GenericGroup();
     ctx->wtails = GenericGroup();
+    ctx->xtails = GenericGroup();
     ctx->longs = GenericGroup();
     ctx->trivial.clear();
     ctx->allpat.clear();
@@ -644,8 +648,19 @@ int build_plan(apm_ctx *ctx) {
     std::vector<uint32_t> raw_off(P);
     for (int i = 0; i < P; ++i) {
         std::string why;
-        const int kv = resolve_kernel(ctx->kernel, ctx->pats[i].m, ctx->k, &why);
+        int kv = resolve_kernel(ctx->kernel, ctx->pats[i].m, ctx->k, &why);
         if (kv == -100) return fail(ctx, APM_ERR_UNSUPPORTED, "pattern %d (length %d): %s", i, ctx->pats[i].m, why.c_str());
+        if (kv == APM_KERNEL_BITPAR && ctx->pats[i].m > 1024) {
+            // one window per wave: the pattern's Eq rows (64 or 128 words per distinct byte, + the "absent" row) must fit LDS
+            bool seen[256] = {false};
+            int nc = 1;
+            for (unsigned char c : ctx->pats[i].bytes) if (!seen[c]) { seen[c] = true; ++nc; }
+            if ((size_t)std::min(nc, 256) * (ctx->pats[i].m <= 2048 ? 64 : 128) * 4 > 60 * 1024) {
+                if (ctx->kernel == APM_KERNEL_BITPAR)
+                    return fail(ctx, APM_ERR_UNSUPPORTED, "pattern %d (length %d): BITPAR beyond 1024 bytes needs an alphabet whose Eq rows fit 60 KiB of LDS", i, ctx->pats[i].m);
+                kv = APM_KERNEL_GENERIC;
+            }
+        }
         ctx->pats[i].kernel = kv;
         raw_off[i] = (uint32_t)ctx->allpat.size();
         ctx->allpat.insert(ctx->allpat.end(), ctx->pats[i].bytes.begin(), ctx->pats[i].bytes.end());
@@ -655,8 +670,10 @@ int build_plan(apm_ctx *ctx) {
         d.m = (uint32_t)ctx->pats[i].m;
         d.byte_off = raw_off[i];
         d.index = (uint32_t)i;
-        if (kv != APM_KERNEL_GENERIC) { // GENERIC scans truncated windows itself (mode 2)
-            GenericGroup &tg = ctx->pats[i].m <= 128 ? ctx->stails : (ctx->pats[i].m <= 512 ? ctx->wtails : ctx->tails);
+        if (kv == APM_KERNEL_BITPAR && ctx->pats[i].m > 1024) {
+            // (the one-window-per-wave kernel evaluates its truncated windows itself)
+        } else if (kv != APM_KERNEL_GENERIC) { // GENERIC scans truncated windows itself (mode 2)
+            GenericGroup &tg = ctx->pats[i].m <= 128 ? ctx->stails : (ctx->pats[i].m <= 512 ? ctx->wtails : ctx->xtails);
             tg.descs.push_back(d);
             tg.m_max = std::max(tg.m_max, ctx->pats[i].m);
         } else {
@@ -669,22 +686,24 @@ int build_plan(apm_ctx *ctx) {
     {
         std::vector<int> idx;
         for (int i = 0; i < P; ++i) if (ctx->pats[i].kernel == APM_KERNEL_BITPAR) idx.push_back(i);
-        // patterns beyond 128 bytes (8- and 16-word columns) get launches of their own: a separate, register-hungry
-        // instantiation of the kernel (apm_launch_bitpar picks it by the launch's m_max)
-        std::stable_partition(idx.begin(), idx.end(), [&](int i) { return ctx->pats[i].m <= 128; });
+        // width classes, each with launches (and kernels) of its own, picked by the launch's m_max (apm_launch_bitpar):
+        // <= 128 bytes (1 - 4 words per column), <= 512 (8 / 16: a register-hungry instantiation), <= 1024 (24 / 32 words,
+        // one-pass column step: apm_bitlong.hip), <= 4096 (one window per WAVE, one pattern per launch: apm_bitlong.hip)
+        auto width_class = [](int m) { return m <= 128 ? 0 : (m <= 512 ? 1 : (m <= 1024 ? 2 : 3)); };
+        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return width_class(ctx->pats[x].m) < width_class(ctx->pats[y].m); });
         size_t pos = 0;
         while (pos < idx.size()) {
             TiledLaunch L;
             L.kind = APM_KERNEL_BITPAR;
-            const bool wide = ctx->pats[idx[pos]].m > 128;
+            const int wclass = width_class(ctx->pats[idx[pos]].m);
             L.tile = 1024;
             bool present[256] = {false};
             int n_codes = 1; // code 0 = absent
             size_t words = 0;
             std::vector<int> members;
-            while (pos < idx.size() && members.size() < 1024) {
+            while (pos < idx.size() && members.size() < (wclass == 3 ? 1u : 1024u)) {
                 const PatternInfo &pi = ctx->pats[idx[pos]];
-                if ((pi.m > 128) != wide) break;
+                if (width_class(pi.m) != wclass) break;
                 bool p2[256];
                 memcpy(p2, present, sizeof p2);
                 int nc = n_codes;
@@ -692,7 +711,7 @@ int build_plan(apm_ctx *ctx) {
                 const int entries = nc > 256 ? 256 : nc;
                 // every member's table is re-laid with the launch's final code count: bound with `entries`
                 size_t w_total = 0;
-                auto stride_of = [](int m) { const int w = (m + 31) / 32; return w <= 2 ? w : (w <= 4 ? 4 : (w <= 8 ? 8 : 16)); };
+                auto stride_of = [](int m) { const int w = (m + 31) / 32; return w <= 2 ? w : (w <= 4 ? 4 : (w <= 8 ? 8 : (w <= 16 ? 16 : (w <= 24 ? 24 : (w <= 32 ? 32 : (w <= 64 ? 64 : 128)))))); };
                 for (int mi : members) w_total += (size_t)entries * stride_of(ctx->pats[mi].m);
                 w_total += (size_t)entries * stride_of(pi.m);
                 if (!members.empty() && w_total * 4 > APM_LDS_TABLE_BUDGET) break;
@@ -712,8 +731,8 @@ int build_plan(apm_ctx *ctx) {
                 const PatternInfo &pi = ctx->pats[mi];
                 ApmPatDesc d{};
                 d.m = (uint32_t)pi.m;
-                const uint32_t w32 = (uint32_t)((pi.m + 31) / 32);      // words of the bit vector: 1, 2, 3, 4, then 8 and 16
-                d.w = w32 <= 4 ? w32 : (w32 <= 8 ? 8u : 16u);           // (the rows past m never reach the distance)
+                const uint32_t w32 = (uint32_t)((pi.m + 31) / 32);      // words of the bit vector: 1, 2, 3, 4, then 8, 16, 24, 32; one window
+                d.w = w32 <= 4 ? w32 : (w32 <= 8 ? 8u : (w32 <= 16 ? 16u : (w32 <= 24 ? 24u : (w32 <= 32 ? 32u : (w32 <= 64 ? 64u : 128u))))); // per wave: 64, 128 (the rows past m never reach the distance)
                 d.stride = d.w == 3 ? 4 : d.w;
                 d.index = (uint32_t)mi;
                 d.byte_off = 0;
@@ -998,6 +1017,7 @@ int build_plan(apm_ctx *ctx) {
         if ((rc = upload_vec(ctx, &ds.d_tail_descs, ctx->tails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_stail_descs, ctx->stails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_wtail_descs, ctx->wtails.descs))) return rc;
+        if ((rc = upload_vec(ctx, &ds.d_xtail_descs, ctx->xtails.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_long_descs, ctx->longs.descs))) return rc;
         if ((rc = upload_vec(ctx, &ds.d_trivial, ctx->trivial))) return rc;
         HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
@@ -1365,6 +1385,26 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
     }
     for (size_t t = 0; t < ctx->tiled.size(); ++t) {
         const TiledLaunch &L = ctx->tiled[t];
+        if (L.kind == APM_KERNEL_BITPAR && L.m_max > 1024) { // one window per wave, one pattern per launch: full and truncated windows alike
+            ApmScanArgs a{};
+            a.text = d_text;
+            a.avail = avail;
+            a.jb = jb;
+            a.je = je;
+            a.nrel = nrel;
+            a.tile0 = jb;
+            a.pats = ds.tiled[t].d_descs;
+            a.tables = ds.tiled[t].d_tables;
+            a.lut = ds.tiled[t].d_lut;
+            a.counts = d_counts;
+            a.n_pats = 1;
+            a.k = ctx->k;
+            a.table_words = (int)L.tables.size();
+            a.pos = sink;
+            HIP_TRY(ctx, apm_launch_bitlong(a, L.m_max, ds.stream));
+            { const int nrc = note_launch(ctx, ds, "bitpar"); if (nrc) return nrc; }
+            continue;
+        }
         const int64_t je_l = std::min<int64_t>(je, nrel - L.m_min + 1);
         if (je_l <= jb) continue;
         if (L.kind == APM_KERNEL_BANDED) {
@@ -1506,6 +1546,20 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
         tw.k = ctx->k;
         tw.pos = sink;
         HIP_TRY(ctx, apm_launch_tail_wide(tw, (int)ctx->wtails.descs.size(), ds.stream));
+        { const int nrc = note_launch(ctx, ds, "tail"); if (nrc) return nrc; }
+    }
+    if (!ctx->xtails.descs.empty() && nrel - (int64_t)ctx->xtails.m_max + 1 < je) { // ... of the 512 < m <= 1024 patterns
+        ApmTailArgs tw{};
+        tw.text = d_text;
+        tw.jb = jb;
+        tw.je = je;
+        tw.nrel = nrel;
+        tw.pats = ds.d_xtail_descs;
+        tw.bytes = ds.d_allpat;
+        tw.counts = d_counts;
+        tw.k = ctx->k;
+        tw.pos = sink;
+        HIP_TRY(ctx, apm_launch_tail_xwide(tw, (int)ctx->xtails.descs.size(), ds.stream));
         { const int nrc = note_launch(ctx, ds, "tail"); if (nrc) return nrc; }
     }
     if (!ctx->trivial.empty()) {

@@ -19,6 +19,9 @@
  * back to the LDS-tile kernels of apm_kernels.hip for unaligned pointers.
  */
 #include <algorithm>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "apm_device.h"
 #include "apm_sieve.h"
 
@@ -43,6 +46,20 @@
 #ifndef APM_FUSED_PIPE
 #define APM_FUSED_PIPE 1 /* the same for the fused form (1 and 2 equal for sampled sets; 2 costs registers) */
 #endif
+
+// Raise a kernel's dynamic-LDS limit to the whole CU ONCE per (kernel, device): hipFuncSetAttribute is a host call of tens of
+// microseconds, and in front of every launch it showed as kernel time on small inputs (the stream idles while the host works)
+static void apm_ensure_max_lds(const void *fn) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &d : done)
+        if (d.first == fn && d.second == dev) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.emplace_back(fn, dev);
+}
 
 typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) uint32_t apm_lds_u32; // LDS dword, for constant-base accesses
@@ -254,8 +271,29 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
             }
         }
     }
-    if constexpr (CF)
-        if (a.blist && bl_n) bl_flush();
+    if constexpr (CF) {
+        // what is left pending when the wave's run ends leaves with ONE atomic per WORKGROUP: the waves of a launch end
+        // together, and 8192 of them adding to one counter took 0.09 ms -- twice the whole sieve of a 256 MiB text (round 3
+        // measurement; the adds serialise at ~90 per microsecond).  The per-wave code strips are free by now: each wave
+        // parks its pending numbers in its own, thread t then copies entry t % 64 of wave t / 64.
+        if (a.blist) { // (workgroup-uniform)
+            if ((uint32_t)lane < bl_n) st[lane] = bl_pend;
+            if (lane == 0) st[64] = bl_n;
+            __syncthreads();
+            uint32_t *wg = reinterpret_cast<uint32_t *>(smem + 32768 + a.cf_len); // wave w's strip: wg + w * (APM_CF_WAVE_BYTES / 4)
+            const uint32_t nw = (uint32_t)(THREADS / 64);
+            uint32_t before = 0, total = 0;
+            for (uint32_t w = 0; w < nw; ++w) {
+                const uint32_t cw = wg[w * (APM_CF_WAVE_BYTES / 4) + 64];
+                if (w < (uint32_t)wv) before += cw;
+                total += cw;
+            }
+            uint32_t *gbase = wg + 65; // (wave 0's strip, behind its own entries)
+            if (tid == 0 && total) *gbase = __hip_atomic_fetch_add(a.blist_ctr, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if ((uint32_t)lane < bl_n) a.blist[*gbase + before + (uint32_t)lane] = bl_pend;
+        }
+    }
 }
 
 __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve2_kernel(ApmSieve2Args a) {
@@ -329,7 +367,7 @@ int apm_sieve2cf_geometry(int cf_len, int *threads) {
     const void *fn = (const void *)apm_sieve2cf_kernel;
     int best_waves = 0, best_blocks = 0;
     *threads = 0;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    apm_ensure_max_lds(fn);
 #ifdef APM_MEASURE
     static const int forced = getenv("APM_CF_THREADS") ? atoi(getenv("APM_CF_THREADS")) : 0;
 #else
@@ -368,7 +406,7 @@ hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
         const int64_t cap = (int64_t)n_cu * a.cf_blocks_per_cu;
         const int64_t nb = want < cap ? want : cap;
         args.n_main_blocks = (int)nb;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)apm_sieve2cf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); // (per device)
+        if (lds > 48 * 1024) apm_ensure_max_lds((const void *)apm_sieve2cf_kernel); // (per device: the geometry query ran on one)
         return hipLaunchKernel((const void *)apm_sieve2cf_kernel, dim3((unsigned)(nb + a.n_tail)), dim3((unsigned)threads), kargs, lds, s);
     }
     const size_t lds = 32768;
@@ -653,7 +691,10 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     const uint32_t NB = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : (listed ? n_listed : (uint32_t)a.n_mask_blocks);
     // blocks per chunk: a short list is dealt block by block (cfg5: 10 K listed blocks for 4 K waves -- with chunks of 8 most
     // waves got none and the rest walked theirs one load after the other: 0.072 ms against 0.036)
-    const uint32_t CH = SAMPLED ? APM_WORK_CH8 : (listed ? 1u : APM_WORK_CH);
+    // (and a short text in chunks small enough that every wave gets a few: 64 MiB in chunks of 8 left two waves of three idle)
+    const uint32_t n_waves_launch = (uint32_t)(FUSED ? sv->n_main_blocks : (int)gridDim.x) * (uint32_t)(THREADS / 64);
+    const uint32_t ch_fit = NB / (4u * n_waves_launch);
+    const uint32_t CH = SAMPLED ? APM_WORK_CH8 : (listed ? 1u : (ch_fit >= APM_WORK_CH ? APM_WORK_CH : (ch_fit < 1u ? 1u : ch_fit)));
     const uint32_t NC = (NB + CH - 1u) / CH;
     // NG = min(APM_WORK_GROUPS, waves of the launch): no group without a wave.  Workgroups go round the XCDs, so the low
     // bits of the wave number alone would tie a group to one XCD and one wave slot: fold the higher bits in
@@ -1106,7 +1147,7 @@ int apm_fused_geometry(const ApmFusedArgs &a, int *threads) {
     int best_waves = 0, best_blocks = 0;
     *threads = 0;
     if (!fn) return 0;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    apm_ensure_max_lds(fn);
 #ifdef APM_MEASURE
     static const int forced = getenv("APM_FUSED_THREADS") ? atoi(getenv("APM_FUSED_THREADS")) : 0;
 #else
@@ -1143,7 +1184,7 @@ hipError_t apm_launch_fused(const ApmFusedArgs &a, int threads, int max_blocks, 
 #ifdef APM_MEASURE
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.v.skip_mask = atoi(e);
 #endif
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); // (per device: the geometry query ran on one)
+    if (lds > 48 * 1024) apm_ensure_max_lds(fn); // (per device: the geometry query ran on one)
     args.v.work_groups = (int)std::min<int64_t>(APM_WORK_GROUPS, nb * (threads / 64));
     args.v.work_epoch = *work_epoch;
     void *kargs[] = {&args};

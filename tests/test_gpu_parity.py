@@ -15,7 +15,7 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 VARIANTS = ["auto", "banded", "bitpar", "wavefront", "generic"]
-MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 512, "wavefront": 256, "banded": 256}
+MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 4096, "wavefront": 256, "banded": 512}
 
 
 def _supported(variant, m, k):
@@ -445,7 +445,8 @@ def test_full_size_counts_pinned_by_full_dp_kernel(ctx, apm, cfg):
 def test_auto_routes_long_loose_patterns_to_bitpar(ctx, apm):
     """m <= 512 where BANDED does not apply (k > 7 or pieces shorter than 4 bytes): the bit-vector kernel with columns of
     up to 16 words, not the global-memory GENERIC one (nor the 14 x slower wavefront kernel, which AUTO no longer picks);
-    m > 512 stays GENERIC; counts = the reference's (golden)."""
+    longer patterns too, up to 4096 bytes (24 / 32-word columns, then one window per wave); beyond that, and for long
+    patterns over big alphabets, GENERIC; counts = the reference's (golden)."""
     for name in ("chrY_loose_long_k60", "chrY_loose_long_k8", "dna20k_loose_long_k9"):
         c = next(c for c in CASES if c["name"] == name)
         ctx.set_kernel("auto")
@@ -455,16 +456,25 @@ def test_auto_routes_long_loose_patterns_to_bitpar(ctx, apm):
         assert ctx.count_buffer(H.case_text(c)) == c["counts"]
     ctx.set_patterns([b"A" * 300], 100)
     assert ctx.pattern_kernel(0) == 3
-    ctx.set_patterns([b"A" * 600], 100)
+    for m in (600, 1024, 1025, 2048, 4096):
+        ctx.set_patterns([b"A" * m], 100)
+        assert ctx.pattern_kernel(0) == 3, m
+    ctx.set_patterns([b"A" * 4097], 100)
+    assert ctx.pattern_kernel(0) == 1
+    ctx.set_patterns([bytes(range(256)) * 8], 100)      # 2048 bytes over 256 distinct ones: the Eq rows do not fit LDS
     assert ctx.pattern_kernel(0) == 1
 
 
-@pytest.mark.parametrize("m,k", [(129, 40), (200, 9), (256, 64), (257, 3), (300, 20), (400, 150), (512, 8)])
+@pytest.mark.parametrize("m,k", [(129, 40), (200, 9), (256, 64), (257, 3), (300, 20), (400, 150), (512, 8),
+                                 (513, 5), (600, 30), (700, 12), (768, 200), (769, 9), (1000, 40), (1024, 6),
+                                 (1025, 6), (1300, 25), (2047, 11), (2048, 300), (2049, 8), (3000, 50), (4096, 16)])
 def test_wide_bitvector_columns_vs_oracle(ctx, apm, m, k):
-    """BITPAR with 8- and 16-word columns (129 <= m <= 512): planted occurrences with substitutions and indels in 60 KB of
+    """BITPAR beyond 128 bytes: 8- and 16-word columns (<= 512), 24 / 32 words with the one-pass column step (<= 1024), one
+    window per wave (<= 4096: 32- and 64-bit rows per lane).  Planted occurrences with substitutions and indels in 60 KB of
     DNA, truncated tail windows included; AUTO and forced BITPAR == the CPU oracle (and == GENERIC)."""
     rnd = random.Random(7 * m + k)
-    n = 60000
+    banded = 8 * k <= m                                      # the oracle's banded form (pinned by the goldens) where the band is narrow
+    n = 60000 if m <= 512 else max(3 * m + 1000, min(60000, int((2e10 if banded else 4e10) / (m * (2 * k + 1) if banded else m * m))))
     text = bytearray(rnd.choice(b"ACGT") for _ in range(n))
     pat = bytes(rnd.choice(b"ACGT") for _ in range(m))
     for i in range(12):
@@ -482,7 +492,7 @@ def test_wide_bitvector_columns_vs_oracle(ctx, apm, m, k):
         o = n - m - 3 if i == 0 else rnd.randrange(0, n - m)     # one right at the end of the text
         text[o:o + m] = w
     text = bytes(text)
-    want = H.oracle_counts(text, [pat], k)
+    want = H.oracle_counts(text, [pat], k, banded=banded)
     assert want[0] >= 1
     for variant in ("auto", "bitpar", "generic"):
         ctx.set_kernel(variant)
