@@ -47,7 +47,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # wave64 instruction in 2 cycles per SIMD, everything else the scan kernels use (packed 16-bit v_pk_*, v_min*, DPP moves,
 # v_alignbit/bfe/lshl_or/and_or/perm/mad24/dot4, v_lshlrev) in 4: 7.0e13 vs 3.8e13 lane-ops/s.
 VALU_PEAK_LANE_OPS = 7.0e13          # simple class (the chip's integer VALU peak as measured)
-VALU_PACKED_CLASS_LANE_OPS = 3.8e13  # packed / DPP / 3-operand class: what the full-DP kernels are made of
+VALU_PACKED_CLASS_LANE_OPS = 3.8e13  # packed / DPP / 3-operand / carry class
+# Share of the 2-cycle class among the VALU instructions of the kernels' loops, from the gfx950 disassembly
+# (tools/valu_mix.py -> profiles/r03/valu_mix.txt).  A kernel's VALU ceiling is the rate of ITS mix:
+# 1 / (f2 / peak2 + (1 - f2) / peak4) lane-ops/s -- so no fraction can exceed 1 unless a count or a class is wrong.
+VALU_MIX_F2 = {"wavefront": 0.280, "bitpar": 0.675}
+
+
+def valu_ceiling(kernel):
+    f2 = VALU_MIX_F2[kernel]
+    return 1.0 / (f2 / VALU_PEAK_LANE_OPS + (1.0 - f2) / VALU_PACKED_CLASS_LANE_OPS)
 
 
 def parse():
@@ -370,8 +379,8 @@ def main():
                 t_s = ms[-1] * 1e-3
                 variants["bitpar"] = {"cells_evaluated_per_s": cells / t_s, "kernel_ms": ms[-1], "sample": "full size",
                                       "counts_equal_headline": bool(ok),
-                                      "valu_frac": bitpar_wave_instr(lens, positions) * 64 / t_s / VALU_PEAK_LANE_OPS,
-                                      "valu_frac_of_4cycle_class": bitpar_wave_instr(lens, positions) * 64 / t_s / VALU_PACKED_CLASS_LANE_OPS,
+                                      "valu_lane_ops_per_s": bitpar_wave_instr(lens, positions) * 64 / t_s,
+                                      "valu_frac": bitpar_wave_instr(lens, positions) * 64 / t_s / valu_ceiling("bitpar"),
                                       "hbm_frac": shard_bytes / t_s / 1e9 / HBM_PEAK_GBS}
                 rec["counts_equal_bitpar"] = bool(ok)
             if max(lens) <= 256:
@@ -393,8 +402,8 @@ def main():
                 variants["wavefront"] = {"cells_evaluated_per_s": sl * per_pos / t_s, "kernel_ms": ms[-1],
                                          "sample": "first %d window starts of the shard" % sl,
                                          "counts_equal_headline": bool(scratch.cpu().tolist() == ref_slice),
-                                         "valu_frac": wavefront_wave_instr(lens, float(sl)) * 64 / t_s / VALU_PEAK_LANE_OPS,
-                                         "valu_frac_of_4cycle_class": wavefront_wave_instr(lens, float(sl)) * 64 / t_s / VALU_PACKED_CLASS_LANE_OPS,
+                                         "valu_lane_ops_per_s": wavefront_wave_instr(lens, float(sl)) * 64 / t_s,
+                                         "valu_frac": wavefront_wave_instr(lens, float(sl)) * 64 / t_s / valu_ceiling("wavefront"),
                                          "hbm_frac": sl / t_s / 1e9 / HBM_PEAK_GBS}
             ctx.set_kernel(args.kernel)
             rec["variants"] = variants
@@ -471,9 +480,13 @@ def main():
         line["cpu_baseline_all_cores"] = cpu_all
     if per_config:
         line["per_config"] = per_config
-    line["valu_peak"] = {"lane_ops_per_s": VALU_PEAK_LANE_OPS, "lane_ops_per_s_4cycle_class": VALU_PACKED_CLASS_LANE_OPS,
-                         "source": "measured: tools/valu_probe.hip (profiles/r02/valu_probe.txt); valu_frac = modelled wave-instructions "
-                                   "(disassembly counts) x 64 lanes / kernel time / peak"}
+    line["valu_peak"] = {"lane_ops_per_s_2cycle_class": VALU_PEAK_LANE_OPS, "lane_ops_per_s_4cycle_class": VALU_PACKED_CLASS_LANE_OPS,
+                         "share_of_2cycle_class": VALU_MIX_F2,
+                         "ceiling_lane_ops_per_s": {kname: valu_ceiling(kname) for kname in VALU_MIX_F2},
+                         "source": "class rates measured by tools/valu_probe.hip (profiles/r02/valu_probe.txt); class mix of each kernel's loops from "
+                                   "the gfx950 disassembly (tools/valu_mix.py, profiles/r03/valu_mix.txt); valu_frac = VALU wave-instructions "
+                                   "(per-column counts that matched SQ_INSTS_VALU within 3 %: profiles/r02/pmc_fulldp_cfg2.txt) x 64 lanes / "
+                                   "kernel time / the ceiling of the kernel's own mix"}
 
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -789,6 +789,29 @@ def test_bench_two_ranks_equal_one_rank():
     assert a["planted_occurrences_found"] and b["planted_occurrences_found"]
 
 
+def test_bench_two_ranks_run_the_whole_cfg4_and_cfg5():
+    """bench.py at N > 1 also times BASELINE.json configs[3..4] as they are -- ONE text of 2^33 bytes cut into N owner ranges,
+    pattern sets planted in that text, the partial counts all-reduced -- beside the weak-scaled headline.  Rehearsed with two
+    ranks on this one GPU over gloo (4 GiB of text per rank: the pipeline scans it in pieces)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([os.sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(H.ROOT, "bench.py"),
+                          "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants"],
+                         capture_output=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr.decode()[-2000:]
+    b = json.loads(two.stdout.decode().strip().splitlines()[-1])
+    assert b["n_gpus"] == 2 and b["config"]["workload"].startswith("cfg3") and b["planted_occurrences_found"]
+    for name in ("cfg4", "cfg5"):
+        r = b["per_config"][name]
+        assert "the whole text" in r["workload"] and r["text_bytes_total"] == 1 << 33 and r["text_bytes_per_gpu"] == 1 << 32
+        assert r["planted_occurrences_found"] and r["value"] > 0 and r["roofline"]["frac"] > 0
+
+
 # ---------------------------------------------------------------- filter corner cases (chains, overflow, big k)
 @pytest.mark.parametrize("variant", ["auto", "banded"])
 def test_repeated_pieces_and_identical_patterns(ctx, apm, variant):
