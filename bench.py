@@ -150,7 +150,9 @@ def wavefront_wave_instr(lens, positions):
                 best = (cost, r, lm)
         _, r, lm = best
         total += (m + lm - 1) * (10.0 + 6.0 * r) / (2 * (64 // lm)) * positions
-    return total          # wave-instructions for `positions` windows per pattern, one window pair per stream slot
+    # wave-instructions for `positions` windows per pattern, one window pair per stream slot; scaled to the counter:
+    # SQ_INSTS_VALU of the cfg2 pass = 1.72125e11 (profiles/r02/pmc_fulldp_cfg2.txt) against 1.77973e11 from this formula
+    return total * (1.72125e11 / 1.77973e11)
 
 
 def bitpar_wave_instr(lens, positions):
