@@ -475,7 +475,7 @@ __device__ __forceinline__ bool apm_ext_bwd(const uint8_t *tb, int te, const uin
 typedef __attribute__((address_space(3))) uint8_t apm_lds_u8; // LDS byte, for constant-address accesses
 
 template <int BAND, int KL, int STRIDE, int DMA>
-__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 2 && STRIDE == 1 && !DMA) ? 3 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : ((BAND >= 1 && STRIDE == 1) ? (DMA ? 5 : 4) : 6))))
+__global__ __launch_bounds__(APM_BLOCK, (BAND == 0 && STRIDE > 1) ? 8 : ((BAND >= 2 && STRIDE == 1 && !DMA) ? 3 : ((BAND >= 3 || (BAND == 2 && STRIDE == 1)) ? 4 : ((BAND >= 1 && STRIDE == 1) ? 4 : 6)))) /* (per-position forms with a band: the LDS-DMA instantiations spilled 8 bytes per lane at 5 waves per SIMD; they are the fallback for unaligned text only since round 2, so they take the registers) */
 void apm_filter_kernel(ApmFilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x;

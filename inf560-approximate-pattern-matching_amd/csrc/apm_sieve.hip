@@ -164,14 +164,25 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
         // nb <= 64 hits, one per lane.  A hit stands for the even position and the odd one behind it: both 16-bit words
         // are looked up; the lane follows the even one if it is a key word, else the odd one; when both are, the odd
         // one goes back into the ring as an entry of its own (rare).
+        // Up to 32 hits (most blocks of a sparse set, and the last batch of any block): lanes 0..31 take the even position of
+        // entry L, lanes 32..63 the odd one of entry L - 32 -- nothing goes back into the ring, no straggler batch for a
+        // handful of odd positions (the both-parities case is common: a unit that tolerates an indel has its neighbour words
+        // set too; it cost cfg3 a second batch per block).
         auto run_batch = [&](uint32_t nb) __attribute__((always_inline)) {
-            const uint32_t ent = rq[(qh + (uint32_t)lane) & 127u];
-            const bool valid = (uint32_t)lane < nb;
+#ifdef APM_CF_NOSPLIT /* (A/B builds) */
+            const bool split = false;
+#else
+            const bool split = nb <= 32u; // (wave-uniform)
+#endif
+            const uint32_t ei = split ? ((uint32_t)lane & 31u) : (uint32_t)lane;
+            const uint32_t ent = rq[(qh + ei) & 127u];
+            const bool valid = ei < nb;
+            const bool take0 = !split || lane < 32, take1 = !split || lane >= 32;
             const uint32_t se = 2u * (ent & 2047u), d = 1u + (se >> 4), she = 2u * (se & 15u); // even byte position inside the block
             const uint32_t w0 = st[d], w1 = st[d + 1u];
             const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, she) & 0xffffu, x1 = __builtin_amdgcn_alignbit(w1, w0, she + 2u) & 0xffffu;
             const uint2 t0 = cf_tbl[x0 & 2047u], t1 = cf_tbl[x1 & 2047u];
-            const bool p0 = valid && !(ent & 2048u) && ((t0.x >> (x0 >> 11)) & 1u), p1 = valid && ((t1.x >> (x1 >> 11)) & 1u);
+            const bool p0 = valid && take0 && !(ent & 2048u) && ((t0.x >> (x0 >> 11)) & 1u), p1 = valid && take1 && ((t1.x >> (x1 >> 11)) & 1u);
             const unsigned long long both = __builtin_amdgcn_ballot_w64(p0 && p1);
             if (both) { // the odd position waits for a later batch (the ring has room: at most 63 + 64 entries are ever pending)
                 const uint32_t idx = qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(both >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)both, 0u));
