@@ -128,6 +128,18 @@ int apm_set_stream(apm_ctx *ctx, void *hip_stream);
 int apm_set_patterns(apm_ctx *ctx, int n_patterns, const char *const *pat,
                      const int *len, int k);
 int apm_set_kernel(apm_ctx *ctx, int kernel /* apm_kernel */);
+/* How a multi-device context (apm_create, more than one device) divides the work.
+ *   APM_PARTITION_TEXT      (default) the text is cut into owner ranges with a halo, every device scans its range for
+ *                           all patterns, the partial counts are summed (RCCL all-reduce): the replacement of the
+ *                           reference's DB_OVER_RANKS (src/database_over_ranks.c:141-195), without its seam over-count
+ *   APM_PARTITION_PATTERNS  the pattern list is cut into contiguous slices, every device scans the WHOLE text for its
+ *                           slice, nothing is reduced: the replacement of PATTERNS_OVER_RANKS
+ *                           (src/patterns_over_ranks.c:160-182); pays when the text is short and the patterns are many
+ * Counts are the same either way.  No effect on single-device contexts.  The device-pointer entry points
+ * (apm_count_shard_device, apm_set_stream) remain single-device calls. */
+#define APM_PARTITION_TEXT 0
+#define APM_PARTITION_PATTERNS 1
+int apm_set_partition(apm_ctx *ctx, int partition);
 
 /* ---- whole-text counting: replaces invoke_kernel+write_kernel_result and
  *      initializeGPU+getGPUResult.  counts[n_patterns], host, overwritten. ---- */

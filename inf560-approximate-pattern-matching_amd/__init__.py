@@ -25,7 +25,7 @@ KERNEL_IDS = {v: k for k, v in KERNEL_NAMES.items()}
 # every symbol include/apm.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "apm_device_count", "apm_abi_version", "apm_create", "apm_create_on_device", "apm_destroy",
-    "apm_last_error", "apm_set_stream", "apm_set_patterns", "apm_set_kernel", "apm_count_buffer",
+    "apm_last_error", "apm_set_stream", "apm_set_patterns", "apm_set_kernel", "apm_set_partition", "apm_count_buffer",
     "apm_count_file", "apm_find_buffer", "apm_count_shard_device", "apm_shard_range", "apm_synth_fill_device",
     "apm_synth_fill_host", "apm_count_synthetic", "apm_set_timing", "apm_get_timing", "apm_get_launch_times", "apm_get_stat",
     "apm_pattern_kernel",
@@ -78,6 +78,7 @@ def load_library():
         "apm_set_stream": (i32, [vp, vp]),
         "apm_set_patterns": (i32, [vp, i32, c.POINTER(c.c_char_p), c.POINTER(i32), i32]),
         "apm_set_kernel": (i32, [vp, i32]),
+        "apm_set_partition": (i32, [vp, i32]),
         "apm_count_buffer": (i32, [vp, vp, u64, c.POINTER(u64)]),
         "apm_count_file": (i32, [vp, c.c_char_p, c.POINTER(u64)]),
         "apm_find_buffer": (i32, [vp, vp, u64, i32, c.POINTER(u64), u64, c.POINTER(u64)]),
@@ -177,6 +178,11 @@ class ApmContext:
         if isinstance(kernel, str):
             kernel = KERNEL_IDS[kernel]
         self._check(self._lib.apm_set_kernel(self._ctx, kernel))
+
+    def set_partition(self, partition):
+        """"text" (default: owner ranges of the text, counts summed) or "patterns" (slices of the pattern list, every
+        device scans the whole text) -- multi-device contexts only"""
+        self._check(self._lib.apm_set_partition(self._ctx, {"text": 0, "patterns": 1}.get(partition, partition)))
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.apm_set_stream(self._ctx, ctypes.c_void_p(stream_ptr)))

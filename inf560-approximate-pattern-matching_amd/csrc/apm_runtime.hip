@@ -229,6 +229,11 @@ struct apm_ctx {
     apm_timing timing{};
     RcclApi rccl;
     bool multi = false; // created by apm_create (single process, >=1 devices)
+    // PATTERN-SHARDED partition (apm_set_partition): one single-device child context per device, child g holds the patterns
+    // [pat_first[g], pat_first[g + 1]) and scans the WHOLE text; the count vectors are disjoint, nothing is reduced
+    int partition = APM_PARTITION_TEXT;
+    std::vector<apm_ctx *> children;
+    std::vector<int> pat_first; // children.size() + 1 entries
     // apm_count_file: pinned staging ring (kept for the life of the context) and its "copied out" events
     static constexpr int N_STAGE = 32;                 // two per reader thread, allocated on first use
     static constexpr size_t STAGE_BYTES = (size_t)8 << 20;
@@ -1954,6 +1959,8 @@ int apm_create_on_device(apm_ctx **ctx, int device_id) {
 
 void apm_destroy(apm_ctx *ctx) {
     if (!ctx) return;
+    for (apm_ctx *ch : ctx->children) apm_destroy(ch);
+    ctx->children.clear();
     if (ctx->rccl.ready)
         for (void *c : ctx->rccl.comms) if (c) ctx->rccl.CommDestroy(c);
     for (auto &ds : ctx->devs) {
@@ -1984,6 +1991,86 @@ int apm_set_stream(apm_ctx *ctx, void *hip_stream) {
     return APM_OK;
 }
 
+static bool pattern_sharded(const apm_ctx *ctx) { return ctx->partition == APM_PARTITION_PATTERNS && ctx->devs.size() > 1; }
+
+// (re)build the children of a pattern-sharded context from ctx->pats / ctx->k / ctx->kernel: contiguous slices of the
+// pattern list, as even as they come (the replacement of /root/reference/src/patterns_over_ranks.c:160-182, where the
+// master dealt patterns to the ranks by a cost model and every rank read the whole file)
+static int build_children(apm_ctx *ctx) {
+    const int G = (int)ctx->devs.size(), P = (int)ctx->pats.size();
+    if (ctx->children.empty()) {
+        ctx->children.assign((size_t)G, nullptr);
+        for (int g = 0; g < G; ++g) {
+            const int rc = create_common(&ctx->children[(size_t)g], std::vector<int>{ctx->devs[(size_t)g].dev}, false);
+            if (rc) return fail(ctx, rc, "pattern-sharded context: device %d: %s", ctx->devs[(size_t)g].dev, g_create_error.c_str());
+        }
+    }
+    ctx->pat_first.assign((size_t)G + 1, 0);
+    for (int g = 0; g <= G; ++g) ctx->pat_first[(size_t)g] = (int)((long long)P * g / G);
+    for (int g = 0; g < G; ++g) {
+        apm_ctx *ch = ctx->children[(size_t)g];
+        const int a = ctx->pat_first[(size_t)g], b = ctx->pat_first[(size_t)g + 1];
+        ch->timing_on = ctx->timing_on;
+        ch->patterns_set = false;
+        if (b <= a) continue; // (fewer patterns than devices)
+        std::vector<const char *> pp;
+        std::vector<int> ll;
+        for (int i = a; i < b; ++i) { pp.push_back(ctx->pats[(size_t)i].bytes.data()); ll.push_back(ctx->pats[(size_t)i].m); }
+        ch->kernel = ctx->kernel;
+        const int rc = apm_set_patterns(ch, b - a, pp.data(), ll.data(), ctx->k);
+        if (rc) return fail(ctx, rc, "%s", ch->err.c_str());
+        for (int i = a; i < b; ++i) ctx->pats[(size_t)i].kernel = ch->pats[(size_t)(i - a)].kernel;
+    }
+    return APM_OK;
+}
+
+// run fn(child, counts of its slice) on every child at once, one host thread per device
+static int for_children(apm_ctx *ctx, uint64_t *counts, const std::function<int(apm_ctx *, uint64_t *)> &fn) {
+    if (!ctx->patterns_set) return fail(ctx, APM_ERR_STATE, "apm_set_patterns has not been called");
+    if (!counts) return fail(ctx, APM_ERR_INVALID, "counts is NULL");
+    const auto t0 = clk::now();
+    const int G = (int)ctx->children.size();
+    std::vector<int> rcs((size_t)G, APM_OK);
+    auto work = [&](int g) {
+        const int a = ctx->pat_first[(size_t)g], b = ctx->pat_first[(size_t)g + 1];
+        if (b > a) rcs[(size_t)g] = fn(ctx->children[(size_t)g], counts + a);
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; ++g) th.emplace_back(work, g);
+    work(0);
+    for (auto &t : th) t.join();
+    ctx->timing = apm_timing{};
+    ctx->timing.n_devices = G;
+    for (int g = 0; g < G; ++g) {
+        if (rcs[(size_t)g]) return fail(ctx, rcs[(size_t)g], "%s", ctx->children[(size_t)g]->err.c_str());
+        if (ctx->pat_first[(size_t)g + 1] <= ctx->pat_first[(size_t)g]) continue;
+        const apm_timing &t = ctx->children[(size_t)g]->timing;
+        ctx->timing.h2d_ms = std::max(ctx->timing.h2d_ms, t.h2d_ms);
+        ctx->timing.kernel_ms = std::max(ctx->timing.kernel_ms, t.kernel_ms);
+        ctx->timing.main_kernel_ms = std::max(ctx->timing.main_kernel_ms, t.main_kernel_ms);
+        ctx->timing.text_bytes += t.text_bytes;
+        ctx->timing.windows += t.windows;
+        ctx->timing.cells_algorithmic += t.cells_algorithmic;
+        ctx->timing.cells_evaluated += t.cells_evaluated;
+        ctx->timing.n_launches += t.n_launches;
+    }
+    ctx->timing.total_ms = ms_since(t0);
+    return APM_OK;
+}
+
+int apm_set_partition(apm_ctx *ctx, int partition) {
+    if (!ctx) return APM_ERR_INVALID;
+    if (partition != APM_PARTITION_TEXT && partition != APM_PARTITION_PATTERNS) return fail(ctx, APM_ERR_INVALID, "unknown partition %d", partition);
+    if (partition == ctx->partition) return APM_OK;
+    ctx->partition = partition;
+    if (ctx->pats.empty()) return APM_OK;
+    ctx->patterns_set = false;
+    const int rc = pattern_sharded(ctx) ? build_children(ctx) : build_plan(ctx);
+    if (rc) return rc;
+    ctx->patterns_set = true;
+    return APM_OK;
+}
+
 int apm_set_patterns(apm_ctx *ctx, int n_patterns, const char *const *pat, const int *len, int k) {
     if (!ctx) return APM_ERR_INVALID;
     if (n_patterns <= 0 || n_patterns > APM_MAX_PATTERNS || !pat || !len)
@@ -2000,7 +2087,7 @@ int apm_set_patterns(apm_ctx *ctx, int n_patterns, const char *const *pat, const
     ctx->pats.swap(v);
     ctx->k = k;
     ctx->patterns_set = false;
-    const int rc = build_plan(ctx);
+    const int rc = pattern_sharded(ctx) ? build_children(ctx) : build_plan(ctx);
     if (rc) return rc;
     ctx->patterns_set = true;
     return APM_OK;
@@ -2009,6 +2096,7 @@ int apm_set_patterns(apm_ctx *ctx, int n_patterns, const char *const *pat, const
 int apm_set_timing(apm_ctx *ctx, int enabled) {
     if (!ctx) return APM_ERR_INVALID;
     ctx->timing_on = enabled != 0;
+    for (apm_ctx *ch : ctx->children) if (ch) ch->timing_on = ctx->timing_on;
     return APM_OK;
 }
 
@@ -2019,11 +2107,12 @@ int apm_set_kernel(apm_ctx *ctx, int kernel) {
     ctx->kernel = kernel;
     if (ctx->patterns_set || !ctx->pats.empty()) {
         ctx->patterns_set = false;
-        const int rc = build_plan(ctx);
+        auto rebuild = [&]() { return pattern_sharded(ctx) ? build_children(ctx) : build_plan(ctx); };
+        const int rc = rebuild();
         if (rc) {
             const std::string msg = ctx->err;
             ctx->kernel = old;
-            if (build_plan(ctx) == APM_OK) ctx->patterns_set = true;
+            if (rebuild() == APM_OK) ctx->patterns_set = true;
             ctx->err = msg;
             return rc;
         }
@@ -2080,6 +2169,7 @@ int apm_count_shard_device(apm_ctx *ctx, const void *d_text, uint64_t text_off, 
 int apm_count_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *counts) {
     if (!ctx) return APM_ERR_INVALID;
     if (!text && n) return fail(ctx, APM_ERR_INVALID, "text is NULL");
+    if (pattern_sharded(ctx)) return for_children(ctx, counts, [&](apm_ctx *ch, uint64_t *c) { return apm_count_buffer(ch, text, n, c); });
     const int G = (int)ctx->devs.size();
     return count_sharded(ctx, n, counts, [&](int g, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
         if (len < (1u << 20)) { // small: one pageable copy (the runtime stages it itself)
@@ -2097,6 +2187,12 @@ int apm_count_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *co
 int apm_count_file(apm_ctx *ctx, const char *path, uint64_t *counts) {
     if (!ctx) return APM_ERR_INVALID;
     if (!path) return fail(ctx, APM_ERR_INVALID, "path is NULL");
+    if (pattern_sharded(ctx)) { // every device reads the whole file (as every rank of the reference's PATTERNS_OVER_RANKS did)
+        const int fdt = open(path, O_RDONLY);
+        if (fdt < 0) return fail(ctx, APM_ERR_IO, "Unable to open the text file <%s>", path);
+        close(fdt);
+        return for_children(ctx, counts, [&](apm_ctx *ch, uint64_t *c) { return apm_count_file(ch, path, c); });
+    }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(ctx, APM_ERR_IO, "Unable to open the text file <%s>", path);
     struct stat st;
@@ -2128,6 +2224,13 @@ int apm_find_buffer(apm_ctx *ctx, const uint8_t *text, uint64_t n, int pattern_i
     if (!ctx->patterns_set) return fail(ctx, APM_ERR_STATE, "apm_set_patterns has not been called");
     if (pattern_index < 0 || pattern_index >= (int)ctx->pats.size() || !n_found || (!positions && capacity) || (!text && n))
         return fail(ctx, APM_ERR_INVALID, "bad argument to apm_find_buffer");
+    if (pattern_sharded(ctx)) { // the device that holds the pattern
+        size_t g = 0;
+        while (g + 1 < ctx->children.size() && pattern_index >= ctx->pat_first[g + 1]) ++g;
+        const int rc = apm_find_buffer(ctx->children[g], text, n, pattern_index - ctx->pat_first[g], positions, capacity, n_found);
+        if (rc) return fail(ctx, rc, "%s", ctx->children[g]->err.c_str());
+        return APM_OK;
+    }
     // run the one pattern through the full-DP kernels with a position sink, then restore the plan
     const std::vector<PatternInfo> saved = ctx->pats;
     const int saved_kernel = ctx->kernel;
@@ -2206,6 +2309,7 @@ void apm_synth_fill_host(uint8_t *dst, uint64_t global_off, uint64_t len, uint64
 
 int apm_count_synthetic(apm_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *counts) {
     if (!ctx) return APM_ERR_INVALID;
+    if (pattern_sharded(ctx)) return for_children(ctx, counts, [&](apm_ctx *ch, uint64_t *c) { return apm_count_synthetic(ch, n, seed, c); });
     return count_sharded(ctx, n, counts, [&](int, DeviceState &ds, uint64_t lo, uint64_t len) -> int {
         HIP_TRY(ctx, apm_launch_synth(ds.d_text, lo, len, seed, ds.stream));
         return APM_OK;
@@ -2215,6 +2319,7 @@ int apm_count_synthetic(apm_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *count
 int apm_get_timing(const apm_ctx *cctx, apm_timing *out) {
     apm_ctx *ctx = const_cast<apm_ctx *>(cctx);
     if (!ctx || !out) return APM_ERR_INVALID;
+    if (pattern_sharded(ctx)) { *out = ctx->timing; return APM_OK; } // (aggregated by the call itself)
     const int rc = collect_event_times(ctx);
     if (rc) return rc;
     *out = ctx->timing;

@@ -66,8 +66,11 @@ int main(int argc, char **argv) {
     argc = w;
 
     /* trailing approach flag of the reference's apm_parallel (src/main.c:66-86) */
-    if (argc >= 2 && (!strcmp(argv[argc - 1], "DB_OVER_RANKS") || !strcmp(argv[argc - 1], "PATTERNS_OVER_RANKS")))
+    int partition = APM_PARTITION_TEXT; /* DB_OVER_RANKS, and the default: the text is sharded over the devices */
+    if (argc >= 2 && (!strcmp(argv[argc - 1], "DB_OVER_RANKS") || !strcmp(argv[argc - 1], "PATTERNS_OVER_RANKS"))) {
+        if (!strcmp(argv[argc - 1], "PATTERNS_OVER_RANKS")) partition = APM_PARTITION_PATTERNS; /* the pattern list is (with --gpus > 1) */
         argc -= 1;
+    }
 
     if (argc < 4) {
         printf("Usage: %s approximation_factor dna_database pattern1 pattern2 ...\n", argv[0]);
@@ -108,6 +111,11 @@ int main(int argc, char **argv) {
     int rc = apm_create(&ctx, n_gpus);
     if (rc != APM_OK) {
         fprintf(stderr, "apm_parallel: %s\n", apm_last_error(NULL));
+        return 1;
+    }
+    if ((rc = apm_set_partition(ctx, partition)) != APM_OK) {
+        fprintf(stderr, "apm_parallel: %s\n", apm_last_error(ctx));
+        apm_destroy(ctx);
         return 1;
     }
     if (kernel != APM_KERNEL_AUTO && (rc = apm_set_kernel(ctx, kernel)) != APM_OK) {

@@ -761,6 +761,64 @@ def test_multi_device_context_rehearsed_on_one_gpu(apm, tmp_path, devices):
         multi.close()
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_pattern_sharded_context_rehearsed_on_one_gpu(apm, tmp_path, devices):
+    """apm_set_partition(APM_PARTITION_PATTERNS): the pattern list cut into contiguous slices, one single-device child
+    context per device, each scanning the WHOLE text (the replacement of the reference's PATTERNS_OVER_RANKS,
+    src/patterns_over_ranks.c:160-182) -- rehearsed with children sharing this one GPU (APM_DEVICES).  Same counts as the
+    golden vectors / the single-device context for buffer, file and generator ingest, more devices than patterns, a
+    forced kernel, match positions, and through the C CLI's trailing PATTERNS_OVER_RANKS."""
+    os.environ["APM_DEVICES"] = devices
+    try:
+        multi = apm.ApmContext(n_devices=0)
+    finally:
+        del os.environ["APM_DEVICES"]
+    G = len(devices.split(","))
+    try:
+        multi.set_partition("patterns")
+        for name in ("x100_k2", "chrY_k3", "cfg1_basic_test"):
+            c = next(c for c in CASES if c["name"] == name)
+            text = H.case_text(c)
+            multi.set_patterns(c["patterns"], c["k"])
+            assert multi.count_buffer(text) == c["counts"], (name, devices)
+            assert multi.timing()["n_devices"] == G
+            f = tmp_path / (name + ".txt")
+            f.write_bytes(text)
+            assert multi.count_file(str(f)) == c["counts"], (name, devices)
+            multi.set_kernel("bitpar")
+            assert multi.count_buffer(text) == c["counts"], (name, "bitpar")
+            multi.set_kernel("auto")
+            multi.set_patterns(c["patterns"][:1], c["k"])                  # fewer patterns than devices
+            assert multi.count_buffer(text) == c["counts"][:1]
+        c = next(c for c in CASES if c["name"] == "chrY_k3")
+        text = H.case_text(c)
+        multi.set_patterns(c["patterns"], c["k"])
+        last = len(c["patterns"]) - 1
+        got_pos, total = multi.find_buffer(text, last)
+        assert got_pos == _oracle_positions(text, c["patterns"][last], c["k"]) and total == c["counts"][last]
+        multi.set_partition("text")                                          # and back: the same context, text-sharded
+        assert multi.count_buffer(text) == c["counts"]
+        multi.set_partition("patterns")
+        wl = H.workloads()
+        cfg = wl.CONFIGS["cfg5"]
+        n, k, seed = 16 << 20, cfg["k"], wl.seed_of(cfg["cid"])
+        pats, planted = wl.make_patterns(n, cfg["lens"], k, seed)
+        with apm.ApmContext(device=0) as one:
+            one.set_patterns(pats, k)
+            want = one.count_synthetic(n, seed)
+        multi.set_patterns(pats, k)
+        assert multi.count_synthetic(n, seed) == want and sum(want) > 0
+    finally:
+        multi.close()
+    c = next(c for c in CASES if c["name"] == "x100_k2")
+    cli = os.path.join(H.PKG_DIR, "host", "apm_parallel")
+    r = subprocess.run([cli, str(c["k"]), c["path"]] + [p.decode() for p in c["patterns"]] + ["PATTERNS_OVER_RANKS", "--gpus", str(G)],
+                       capture_output=True, env=dict(os.environ, APM_DEVICES=devices), timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    got = [int(l.rsplit(":", 1)[1]) for l in r.stdout.decode().splitlines() if l.startswith("Number of matches")]
+    assert got == c["counts"]
+
+
 def test_bench_two_ranks_equal_one_rank():
     """bench.py's N > 1 path (owner-computes shards + halo + all-reduce of the partial counts), rehearsed with two
     ranks sharing this one GPU over gloo (RCCL refuses two ranks on one device): the summed counts must equal the
