@@ -259,23 +259,46 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for i in range(steps):
-            counts = step(i)
-        drain()
-        ev1.record()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        ev_ms = ev0.elapsed_time(ev1)
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        def timed_region():
+            """EXACTLY `steps` steps between barrier + synchronize on both sides; (seconds, max over ranks; event ms)"""
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()
+            c = None
+            for i in range(steps):
+                c = step(i)
+            drain()
+            ev1.record()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return el, ev0.elapsed_time(ev1), c
+
+        # A region of K steps of this path is a few milliseconds (K = 20: 8 ms), and one clock ramp or one descheduled host
+        # thread decides it.  The region is therefore timed REPEATEDLY -- every repeat is exactly K steps, bracketed as the
+        # contract says -- until 0.25 s have been spent (at most 15 repeats; a region of >= 50 ms stands alone), and the MEDIAN
+        # region is reported; all of them are listed in `timed_regions_ms_per_step`.  (All ranks take the same decisions:
+        # the elapsed time they see is the all-reduced maximum.)
+        regions = []
+        spent = 0.0
+        while True:
+            el, ev_ms_r, counts = timed_region()
+            regions.append((el, ev_ms_r))
+            spent += el
+            if el >= 0.05 or spent >= 0.25 or len(regions) >= 15:
+                break
+        regions.sort()
+        elapsed, ev_ms = regions[len(regions) // 2]
         final_counts = counts.cpu().tolist()
 
         # per-launch kernel durations with HIP events on the launch stream (the library stamps the stream behind
@@ -342,6 +365,7 @@ def main():
             "workload": label,
             "value": cells / sec_per_step, "unit": "cells/s", "ms_per_step": sec_per_step * 1e3,
             "event_ms_per_step": ev_ms / steps,
+            "timed_regions": len(regions), "timed_regions_ms_per_step": [r[0] / steps * 1e3 for r in regions],
             "positions_x_patterns_per_s": float(max(0, n_total - k)) * P / sec_per_step,
             "text_bytes_total": n_total, "text_bytes_per_gpu": per_gpu, "patterns": P,
             "pattern_len": sorted(set(lens)), "k": k, "kernel": "+".join(kernel_names),
@@ -472,6 +496,9 @@ def main():
         "counts": head["counts"],
         "planted_occurrences_found": head["planted_occurrences_found"],
         "event_ms_per_step": head["event_ms_per_step"],
+        "timed_regions": head["timed_regions"], "timed_regions_ms_per_step": head["timed_regions_ms_per_step"],
+        "timing_note": "ms_per_step / value = the MEDIAN of `timed_regions` regions of exactly `steps` steps each (every region bracketed "
+                       "by barrier + synchronize; repeated until 0.25 s are spent when one region is shorter than 50 ms)",
         "roofline": head["roofline"],
     }
     for key in ("counts_equal_bitpar", "counts_equal_closed_form_k0", "sieve", "variants"):
