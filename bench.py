@@ -286,7 +286,7 @@ def main():
 
         # A region of K steps of this path is a few milliseconds (K = 20: 8 ms), and one clock ramp or one descheduled host
         # thread decides it.  The region is therefore timed REPEATEDLY -- every repeat is exactly K steps, bracketed as the
-        # contract says -- until 0.25 s have been spent (at most 15 repeats; a region of >= 50 ms stands alone), and the MEDIAN
+        # contract says -- until 0.25 s have been spent (at least 3, at most 15 repeats; a FIRST region of >= 50 ms stands alone), and the MEDIAN
         # region is reported; all of them are listed in `timed_regions_ms_per_step`.  (All ranks take the same decisions:
         # the elapsed time they see is the all-reduced maximum.)
         regions = []
@@ -295,10 +295,10 @@ def main():
             el, ev_ms_r, counts = timed_region()
             regions.append((el, ev_ms_r))
             spent += el
-            if el >= 0.05 or spent >= 0.25 or len(regions) >= 15:
+            if (len(regions) == 1 and el >= 0.05) or (spent >= 0.25 and len(regions) >= 3) or len(regions) >= 15:
                 break
         regions.sort()
-        elapsed, ev_ms = regions[len(regions) // 2]
+        elapsed, ev_ms = regions[(len(regions) - 1) // 2]
         final_counts = counts.cpu().tolist()
 
         # per-launch kernel durations with HIP events on the launch stream (the library stamps the stream behind

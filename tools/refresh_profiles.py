@@ -47,7 +47,7 @@ for cfg in sorted(os.listdir(G)):
     rows = [r for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))) if "apm_" in r["Name"] and "synth" not in r["Name"]]
     dom = max(rows, key=lambda r: float(r["AverageNs"]))["Name"]
     dom_key = next((k for k in per_kernel if dom.startswith(k) or k.startswith(dom[:60])), None)
-    steps = bench["steps"] + bench["warmup"] + bench["steps"]          # timed + warm-up + the event-timed repeat
+    steps = max(v["launches_in_run"] for v in per_kernel.values())      # passes over the shard in the run = launches of a kernel every step has
     total = sum(v["bytes_per_launch"] * v["launches_in_run"] for v in per_kernel.values()) / steps
     traffic["%s:%s" % (cfg, bench["config"]["kernel"])] = dict(
         round=rnd, kernel=dom, traffic_bytes=per_kernel[dom_key]["bytes_per_launch"] if dom_key else None,
