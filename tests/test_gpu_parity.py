@@ -501,6 +501,34 @@ def test_wide_bitvector_columns_vs_oracle(ctx, apm, m, k):
     ctx.set_kernel("auto")
 
 
+@pytest.mark.parametrize("m,k,alphabet", [(600, 9, b"etaoin shrdlucmfwypvbgkqjxz\n"), (1500, 12, bytes(range(32, 112))), (3000, 20, b"ACGTN\n"),
+                                          (4096, 7, bytes(range(1, 41)))])
+def test_long_patterns_over_bigger_alphabets(ctx, apm, m, k, alphabet):
+    """The long bit-vector forms keep one Eq row per distinct pattern byte in LDS (24/32 words per row up to 1024 bytes, 64
+    or 128 beyond): prose-like, 80-letter and 40-letter alphabets, text bytes the pattern does not contain, an occurrence cut
+    by the end of the text (truncated windows).  AUTO == forced BITPAR == the CPU oracle's banded form."""
+    rnd = random.Random(m + k)
+    n = 3 * m + 2000
+    text = bytearray(rnd.choice(alphabet + b"\x00\xff") for _ in range(n))
+    pat = bytearray(rnd.choice(alphabet) for _ in range(m))
+    for o in (17, n - m - 1, n - m + 40):                      # the last one leaves only a truncated window
+        w = bytearray(pat)
+        for _e in range(k - 2):
+            w[rnd.randrange(m)] = rnd.choice(alphabet)
+        del w[m // 3]
+        w.insert(2 * m // 3, rnd.choice(alphabet))
+        text[o:o + m] = w[:max(0, min(m, n - o))]
+    text, pat = bytes(text[:n]), bytes(pat)
+    want = H.oracle_counts(text, [pat], k, banded=True)
+    assert want[0] >= 2
+    for variant in ("auto", "bitpar"):
+        ctx.set_kernel(variant)
+        ctx.set_patterns([pat], k)
+        assert ctx.pattern_kernel(0) == 3
+        assert ctx.count_buffer(text) == want, (variant, m, k)
+    ctx.set_kernel("auto")
+
+
 def test_reference_gpu_entry_points_link_level(tmp_path):
     """include/apm_refshim.h: a C program calls getDeviceCount/setDevice, invoke_kernel/write_kernel_result and
     initializeGPU/getGPUResult exactly as the reference's host files do, linked against libapm_hip.so only."""
