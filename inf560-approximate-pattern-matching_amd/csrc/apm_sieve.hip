@@ -650,7 +650,8 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NSH = 2 * BAND + 1;
-    constexpr uint32_t FLUSH_AT = (64 + NSH - 1) / NSH; // the DP pass runs once it fills a wave: (survivor, shift) items
+    constexpr uint32_t FLUSH_AT = (64 + NSH - 1) / NSH; // survivors that fill a wave of (survivor, shift) items (capacity of the list: apm_verify_scap)
+    (void)FLUSH_AT;
     constexpr int SCAP = apm_verify_scap(BAND);         // capacity of a wave's survivor list: FLUSH_AT - 1 + one round of 64
     uint8_t *s_img = smem + ((FUSED && !SAMPLED) ? 32768 : 0);
     const uint32_t *s_bmp = reinterpret_cast<const uint32_t *>(s_img);
@@ -684,6 +685,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     // DP pass over the wave's survivor list, or moves to the next (batch, parity), or evaluates the predicate once
     // for every lane that still has a key to try at its position. ----
     uint32_t n_surv = 0; // wave-uniform
+    uint32_t item_lo = 0; // wave-uniform: shifts of the list's first survivor that an earlier DP pass has taken already
     // the sieve's 4 KiB blocks are dealt to the waves in equal contiguous runs; a wave compacts the hit masks of its
     // blocks (one dword per lane and block) into a queue of positions and takes 64 of them per batch -- dense lanes
     // across block borders, since the text comes from global memory anyway
@@ -954,10 +956,13 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     bool have_nn = false, ex_nn = true;
     load_win(0u, win_n);
     for (;;) {
-        if (n_surv >= FLUSH_AT || (done && n_surv)) {
-            for (uint32_t w0 = 0; w0 < n_surv * NSH; w0 += 64) { // one (survivor, shift) per lane
-                const uint32_t wi = w0 + (uint32_t)lane;
-                const bool live = wi < n_surv * NSH;
+        // the DP pass takes FULL waves of (survivor, shift) items only -- what is left over (fewer than 64 items, possibly
+        // part of a survivor's shifts: item_lo) waits at the front of the list for the next pass; everything at the end
+        if (n_surv * NSH - item_lo >= 64u || (done && n_surv)) {
+            const uint32_t avail_items = n_surv * NSH - item_lo, proc = done ? avail_items : (avail_items & ~63u);
+            for (uint32_t w0 = 0; w0 < proc; w0 += 64) { // one (survivor, shift) per lane
+                const uint32_t wi = item_lo + w0 + (uint32_t)lane;
+                const bool live = w0 + (uint32_t)lane < proc;
                 const uint2 e = live ? s_surv[wi / NSH] : make_uint2(0u, 0u);
                 const int dl = (int)(wi % NSH) - BAND;
                 uint32_t wpat = 0, wj = 0, word = 0;
@@ -967,7 +972,11 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
 #endif
                 core.count_matches(hit, wpat, wj, word);
             }
-            n_surv = 0;
+            const uint32_t s_first = (item_lo + proc) / NSH, left = n_surv - s_first; // (left <= 22 survivors)
+            const uint2 keep = (uint32_t)lane < left ? s_surv[s_first + (uint32_t)lane] : make_uint2(0u, 0u);
+            if ((uint32_t)lane < left) s_surv[lane] = keep;
+            item_lo = item_lo + proc - s_first * NSH;
+            n_surv = left;
         }
         if (done) break;
         // a lane without a key in hand takes up the next of its (at most two) hit positions: key list by rank
@@ -1055,7 +1064,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
 }
 
 template <int BAND, int THREADS, bool SAMPLED>
-__global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) ? 7 : 4) void apm_verify_kernel(ApmVerifyArgs a) {
+__global__ __launch_bounds__(THREADS, (BAND == 1 && THREADS == 256 && !SAMPLED) ? 6 : 4) void apm_verify_kernel(ApmVerifyArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     apm_verify_body<BAND, THREADS, SAMPLED, false>(a, nullptr, smem);
 }
@@ -1128,7 +1137,7 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
 // FUSED: sieve + verify in one launch (apm_verify_body<.., FUSED = true>; see ApmFusedArgs)
 // ---------------------------------------------------------------------------
 template <int BAND, bool SAMPLED>
-__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND == 0 ? 7 : 5) : (BAND <= 1 ? 6 : 5)) void apm_fused_kernel(ApmFusedArgs f) {
+__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND == 0 ? 7 : 5) : (BAND == 0 ? 6 : 5)) void apm_fused_kernel(ApmFusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if ((int)blockIdx.x >= f.s.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
         apm_tail_body(f.s.tail, (int)blockIdx.x - f.s.n_main_blocks, reinterpret_cast<uint4 *>(smem), (int)threadIdx.x);
