@@ -109,6 +109,12 @@ struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns 
     int m_max = 0, m_min = 0;
     int blocks_per_cu = 0, threads = 256; // launch geometry (occupancy query, cached)
     int fused_blocks_per_cu = 0, fused_threads = 0; // the same for the fused form (threads < 0: it does not fit a CU)
+    // stride 1 with the code filter: the launch has a SIEVE PASS OF ITS OWN -- the 18-bit bitmap of its keys alone and the
+    // code-filter image over its key numbering (ApmSieve2Args::cf_image: tbl | rrec | lrec); empty: the set's shared sieve
+    std::vector<uint32_t> bitmap18;
+    std::vector<uint8_t> cf_image;
+    int cf_o_rrec = 0, cf_o_lrec = 0;
+    int cf_threads = 0, cf_blocks_per_cu = 0; // launch geometry (occupancy query, cached; threads < 0: does not fit a CU)
 };
 
 struct SievePlan {         // ONE text pass (apm_sieve2_kernel) for every per-position key of the pattern set
@@ -119,13 +125,13 @@ struct SievePlan {         // ONE text pass (apm_sieve2_kernel) for every per-po
     double rate = 0;                  // expected hits per lookup on uniform codes (bitmap density)
     std::vector<uint32_t> bitmap;     // 32 KiB over the 18-bit code words of 9-byte windows: dword x & 8191, bit x >> 13
     std::vector<VerifyLaunch> launches;
-    // code filter of the sieve (ApmSieve2Args::cf_image): stride 1 and ONE verify launch -- the head of its image + krec
-    std::vector<uint8_t> cf_image;            // tbl | rrec | lrec
-    int cf_o_rrec = 0, cf_o_lrec = 0;
-    int cf_threads = 0, cf_blocks_per_cu = 0; // launch geometry (occupancy query, cached; threads < 0: does not fit a CU)
+    double weak_frac = 0;             // share of the key words that belong to units the code filter cannot add to
+    bool per_launch_sieve = false;    // stride 1 with the code filter: every verify launch is preceded by its own sieve pass (VerifyLaunch::bitmap18)
 };
 
 struct DevVerify {
+    uint32_t *d_bmp18 = nullptr;   // VerifyLaunch::bitmap18
+    uint8_t *d_cf = nullptr;       // VerifyLaunch::cf_image
     ApmPatDesc *d_descs = nullptr;
     uint8_t *d_image = nullptr;
     uint32_t *d_kinfo = nullptr;
@@ -168,8 +174,7 @@ struct DeviceState {
     uint8_t *d_text = nullptr;
     size_t text_cap = 0;
     hipEvent_t ev_stage[32] = {};             // apm_count_file: staging buffer b copied out (this device's stream)
-    uint32_t *d_sieve_bmp = nullptr;           // sieve bitmap (32 KiB)
-    uint8_t *d_sieve_cf = nullptr;             // the sieve's code-filter image (SievePlan::cf_image)
+    uint32_t *d_sieve_bmp = nullptr;           // sieve bitmap of the whole set (32 KiB)
     std::vector<DevVerify> verify;
     uint32_t *d_masks = nullptr;               // the sieve's hit masks: one dword per lane and 4 KiB block (n / 16 bytes)
     size_t masks_cap = 0;                      // dwords
@@ -335,8 +340,9 @@ void free_device_plan(DeviceState &ds) {
     if (ds.d_trivial) hipFree(ds.d_trivial), ds.d_trivial = nullptr;
     if (ds.d_counts) hipFree(ds.d_counts), ds.d_counts = nullptr;
     if (ds.d_sieve_bmp) hipFree(ds.d_sieve_bmp), ds.d_sieve_bmp = nullptr;
-    if (ds.d_sieve_cf) hipFree(ds.d_sieve_cf), ds.d_sieve_cf = nullptr;
     for (auto &v : ds.verify) {
+        if (v.d_bmp18) hipFree(v.d_bmp18);
+        if (v.d_cf) hipFree(v.d_cf);
         if (v.d_descs) hipFree(v.d_descs);
         if (v.d_image) hipFree(v.d_image);
         if (v.d_kinfo) hipFree(v.d_kinfo);
@@ -463,8 +469,13 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
         }
         return us;
     };
+    static const int cf_env = getenv("APM_SIEVE_CF") ? atoi(getenv("APM_SIEVE_CF")) : 1;
+    const bool cf_on = cf_env && stride == 1;
+    double words_weak = 0, words_strong = 0; // key words of units the code filter can / cannot add to (see `weak` below)
     for (size_t pos = 0; pos < idx.size();) {
         VerifyLaunch V;
+        std::vector<uint8_t> v_seen16(8192, 0);  // this launch's 16-bit code words / 18-bit words (as seen16 / even18 of the set)
+        std::vector<uint32_t> v_even18(8192, 0);
         std::vector<ApmUnit> units; // per key, offsets relative to the pattern
         size_t n_words = 0;         // code words of the launch's units, counted per pattern (>= the distinct ones)
         for (; pos < idx.size(); ++pos) {
@@ -474,8 +485,9 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             // the image must fit a CU's LDS beside the wave buffers of one workgroup, and the slot indices 15 bits:
             // bitmap + prefix (12 KiB), rank -> key and key lists (<= 2 + 2 bytes per word), key records, pattern bytes
             const size_t est = 12288 + 4 * (n_words + pw) + 8 * (V.kinfo.size() + us.size()) + 8 * (V.descs.size() + 1) + V.bytes.size() + (size_t)pi.m + 512;
+            // (with the code filter the launch's sieve pass keeps 8 bytes per key word in LDS beside its 32 KiB bitmap: <= 80 KiB)
             if (!V.descs.empty() && (V.bytes.size() + (size_t)pi.m > 24576 || V.kinfo.size() + us.size() > (stride == 8 ? 2048u : 8192u) || V.descs.size() >= 4096 ||
-                                     est > APM_VERIFY_IMAGE_MAX || n_words + pw >= 0x7000))
+                                     est > APM_VERIFY_IMAGE_MAX || n_words + pw >= 0x7000 || (cf_on && 8 * (n_words + pw) > 80 * 1024)))
                 break;
             n_words += pw;
             ApmPatDesc d{};
@@ -513,11 +525,15 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
                     wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | (uint64_t)(kid | (r << 11)));
                 }
             } else {
+                const size_t wk0 = wk.size();
                 apm_enum_unit_windows(V.bytes.data() + dd.byte_off, u, S.code_shift,
                                       [&](uint32_t xx) { wk.push_back(((uint64_t)rank_key(xx) << 32) | ((uint64_t)xx << 16) | (uint64_t)kid); });
+                // a unit the code filter cannot judge any better than the 8-byte bitmap has: everything it would test lies inside the window
+                const bool weak = (u.side == 0 && u.len <= 9) || (u.side == 1 && u.len == 0 && u.plen <= 9);
+                (weak ? words_weak : words_strong) += (double)(wk.size() - wk0);
                 // the sieve looks at NINE bytes where the key window starts at an even position: the unit's 18-bit words
                 // (a ninth exact byte, or what one edit leaves of the partner there)
-                apm_enum_unit_windows(V.bytes.data() + dd.byte_off, u, S.code_shift, [&](uint32_t x18) { even18[x18 & 8191u] |= 1u << (x18 >> 13); }, 9);
+                apm_enum_unit_windows(V.bytes.data() + dd.byte_off, u, S.code_shift, [&](uint32_t x18) { even18[x18 & 8191u] |= 1u << (x18 >> 13); v_even18[x18 & 8191u] |= 1u << (x18 >> 13); }, 9);
             }
             // packed pre-check record: byte offset of the exact part in the pattern pool | its length << 16 |
             // partner length << 24 (31 = beyond 16) | side << 29
@@ -538,6 +554,7 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
             const uint32_t xx = (uint32_t)(wk[i] >> 16) & 0xffffu;
             bmp16[xx & 2047u] |= 1u << (xx >> 11);
             seen16[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
+            v_seen16[xx & 8191u] |= (uint8_t)(1u << (xx >> 13));
             if (j - i == 1) {
                 r2s.push_back((uint16_t)(0x8000u | (wk[i] & 0x7fffu)));
             } else {
@@ -573,8 +590,20 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
         V.o_kinfo = append(V.kinfo.data(), V.kinfo.size() * 4);
         V.o_pinfo = append(V.pinfo.data(), V.pinfo.size() * 4);
         S.m_max = std::max(S.m_max, V.m_max);
-        // the sieve's code filter works on ONE key numbering: built for the set's first launch, dropped below if there are more
-        if (stride == 1 && S.launches.empty()) {
+        // the launch's own sieve pass (stride 1 with the code filter): the bitmap of ITS keys -- built like the set's below -- and
+        // the code-filter tables over its key numbering.  A big set thus scans the text once per launch group, each pass
+        // with a sparser bitmap and the filter in front of its verify launch: 2000 patterns of 50 bytes, k = 5, took one
+        // sieve + five verify launches of 2.5 - 3 ms per GiB each; a sieve pass is 0.3 and its verify launch then near nothing.
+        if (cf_on) {
+            V.bitmap18.assign(8192, 0u);
+            for (uint32_t x = 0; x < 65536u; ++x) {
+                if (!((v_seen16[x & 8191u] >> (x >> 13)) & 1u)) continue;
+                for (uint32_t f = 0; f < 4; ++f) {
+                    const uint32_t c18 = (x << 2) | f;
+                    V.bitmap18[c18 & 8191u] |= 1u << (c18 >> 13);
+                }
+            }
+            for (uint32_t i = 0; i < 8192u; ++i) V.bitmap18[i] |= v_even18[i];
             std::vector<uint32_t> tbl(4096), rrec, lrec;
             for (int w = 0; w < 2048; ++w) { tbl[2 * w] = bmp16[w]; tbl[2 * w + 1] = prefix[w]; }
             for (size_t i = 0; i < wk.size();) { // (rank order, as r2s above)
@@ -596,22 +625,25 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
                 i = j;
             }
             auto cf_append = [&](const std::vector<uint32_t> &v) {
-                const size_t at = S.cf_image.size(), bytes = v.size() * 4;
-                S.cf_image.resize(at + ((bytes + 15) & ~(size_t)15) + 16, 0); // (+16: a lane without a word reads record 0)
-                if (bytes) memcpy(S.cf_image.data() + at, v.data(), bytes);
+                const size_t at = V.cf_image.size(), bytes = v.size() * 4;
+                V.cf_image.resize(at + ((bytes + 15) & ~(size_t)15) + 16, 0); // (+16: a lane without a word reads record 0)
+                if (bytes) memcpy(V.cf_image.data() + at, v.data(), bytes);
                 return (int)at;
             };
-            S.cf_image.clear();
             cf_append(tbl);
-            S.cf_o_rrec = cf_append(rrec);
-            S.cf_o_lrec = cf_append(lrec);
+            V.cf_o_rrec = cf_append(rrec);
+            V.cf_o_lrec = cf_append(lrec);
+            if (lrec.size() / 2 > 0xffffu) V.cf_image.clear(); // (list indices are 16 bits)
         }
         S.launches.push_back(std::move(V));
     }
-    {
-        static const int cf_env = getenv("APM_SIEVE_CF") ? atoi(getenv("APM_SIEVE_CF")) : 1;
-        if (!cf_env || S.launches.size() != 1) S.cf_image.clear();
-    }
+    S.per_launch_sieve = cf_on && !S.launches.empty();
+    for (const VerifyLaunch &V : S.launches)
+        if (V.cf_image.empty()) S.per_launch_sieve = false;
+    S.weak_frac = words_weak + words_strong > 0 ? words_weak / (words_weak + words_strong) : 0.0;
+    // A single group whose hits nearly all come from such units gains nothing from the filter and pays its instructions
+    // (60 patterns of 16 bytes, k = 3 -- pair units of 8 bytes: 0.395 -> 0.459 ms per 64 MiB); APM_SIEVE_CF=2 keeps it on.
+    if (cf_env != 2 && S.launches.size() == 1 && S.weak_frac > 0.8) S.per_launch_sieve = false;
     // the sieve's bitmap.  Stride 1: over 9-byte windows at EVEN positions -- a key window may start at the even position
     // (the unit's own nine-byte words, apm_enum_unit_windows with W = 9) or at the odd one behind it (its 16-bit word x,
     // the first byte free).
@@ -1028,10 +1060,13 @@ int build_plan(apm_ctx *ctx) {
         HIP_TRY(ctx, hipMalloc((void **)&ds.d_counts, std::max<size_t>((size_t)P * 8, 16)));
         if (ctx->sieve.on) {
             if ((rc = upload_vec(ctx, &ds.d_sieve_bmp, ctx->sieve.bitmap))) return rc;
-            if (!ctx->sieve.cf_image.empty() && (rc = upload_vec(ctx, &ds.d_sieve_cf, ctx->sieve.cf_image))) return rc;
             ds.verify.resize(ctx->sieve.launches.size());
             for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
                 const VerifyLaunch &V = ctx->sieve.launches[v];
+                if (ctx->sieve.per_launch_sieve) {
+                    if ((rc = upload_vec(ctx, &ds.verify[v].d_bmp18, V.bitmap18))) return rc;
+                    if ((rc = upload_vec(ctx, &ds.verify[v].d_cf, V.cf_image))) return rc;
+                }
                 if ((rc = upload_vec(ctx, &ds.verify[v].d_descs, V.descs))) return rc;
                 if ((rc = upload_vec(ctx, &ds.verify[v].d_image, V.image))) return rc;
                 if ((rc = upload_vec(ctx, &ds.verify[v].d_kinfo, V.kinfo))) return rc;
@@ -1297,48 +1332,49 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
             }
             static const int blist_env = getenv("APM_SIEVE_BLIST") ? atoi(getenv("APM_SIEVE_BLIST")) : 1; // (A/B aid: 0 = the verify launches walk every mask row)
             ds.last_mask_blocks = n_mask_blocks;
-            ApmSieve2Args sv{};
-            sv.text = d_text;
-            sv.avail_pad = avail_pad;
-            sv.tile0 = p_lo;
-            sv.nchunks = (p_hi - p_lo + 1023) / 1024;
-            sv.bitmap = reinterpret_cast<const uint4 *>(ds.d_sieve_bmp);
-            sv.code_shift = ctx->sieve.code_shift;
-            sv.stride = ctx->sieve.stride;
-            sv.masks = ds.d_masks;
-            if (!ctx->sieve.cf_image.empty() && ds.d_sieve_cf) { // second stage of the sieve: the code filter
-                SievePlan &S = ctx->sieve;
-                if (!S.cf_threads) {
-                    S.cf_blocks_per_cu = apm_sieve2cf_geometry((int)S.cf_image.size(), &S.cf_threads);
-                    if (S.cf_blocks_per_cu < 1) S.cf_threads = -1; // does not fit a CU
+            // one sieve pass: the set's shared bitmap (v < 0), or launch v's own bitmap with its code filter
+            const uint32_t *blist_ctr = nullptr; // the list counter of the pass in hand (NULL: no list kept)
+            auto sieve_pass = [&](int v) -> int {
+                ApmSieve2Args sv{};
+                sv.text = d_text;
+                sv.avail_pad = avail_pad;
+                sv.tile0 = p_lo;
+                sv.nchunks = (p_hi - p_lo + 1023) / 1024;
+                sv.bitmap = reinterpret_cast<const uint4 *>(v < 0 ? ds.d_sieve_bmp : ds.verify[(size_t)v].d_bmp18);
+                sv.code_shift = ctx->sieve.code_shift;
+                sv.stride = ctx->sieve.stride;
+                sv.masks = ds.d_masks;
+                if (v >= 0) { // second stage of the sieve: the code filter
+                    VerifyLaunch &V = ctx->sieve.launches[(size_t)v];
+                    sv.cf_image = reinterpret_cast<const uint4 *>(ds.verify[(size_t)v].d_cf);
+                    sv.cf_len = (int)V.cf_image.size();
+                    sv.cf_o_rrec = V.cf_o_rrec;
+                    sv.cf_o_lrec = V.cf_o_lrec;
+                    sv.cf_threads = V.cf_threads;
+                    sv.cf_blocks_per_cu = V.cf_blocks_per_cu;
                 }
-                if (S.cf_threads >= 64) {
-                    sv.cf_image = reinterpret_cast<const uint4 *>(ds.d_sieve_cf);
-                    sv.cf_len = (int)S.cf_image.size();
-                    sv.cf_o_rrec = S.cf_o_rrec;
-                    sv.cf_o_lrec = S.cf_o_lrec;
-                    sv.cf_threads = S.cf_threads;
-                    sv.cf_blocks_per_cu = S.cf_blocks_per_cu;
+                // the truncated tail windows ride as extra workgroups beside the scan -- in the code-filter form only a few of
+                // them: its workgroups are big (1024 threads, most of a CU's LDS) and 2000 of them, one per pattern, made the
+                // pass three times as long (256 cost nothing measurable); beyond 512 they get the small launch of their own at the end of the call
+                if (tails_pending && (v < 0 || ctx->stails.descs.size() <= 512)) {
+                    sv.n_tail = (int)ctx->stails.descs.size();
+                    sv.tail = ta;
+                    tails_pending = false;
                 }
-            }
-            if (tails_pending) { // the truncated tail windows ride as extra workgroups beside the scan
-                sv.n_tail = (int)ctx->stails.descs.size();
-                sv.tail = ta;
-                tails_pending = false;
-            }
-            const bool use_blist = blist_env && sv.cf_image != nullptr; // (the list is kept by the code-filter form of the sieve only)
-            if (use_blist) {
-                sv.blist = ds.d_blist;
-                sv.blist_ctr = APM_BLIST_CTR(ds.d_work, ds.sieve_epoch & 1);
-                sv.blist_ctr_next = APM_BLIST_CTR(ds.d_work, (ds.sieve_epoch + 1) & 1);
-            }
-            HIP_TRY(ctx, apm_launch_sieve2(sv, ds.n_cu, ds.stream));
-            if (use_blist) ++ds.sieve_epoch; // (a launch that did not run leaves its counter set as it was: still zero)
-            { const int nrc = note_launch(ctx, ds, "sieve"); if (nrc) return nrc; }
-            for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
+                const bool use_blist = blist_env && sv.cf_image != nullptr; // (the list is kept by the code-filter form of the sieve only)
+                blist_ctr = nullptr;
+                if (use_blist) {
+                    sv.blist = ds.d_blist;
+                    sv.blist_ctr = APM_BLIST_CTR(ds.d_work, ds.sieve_epoch & 1);
+                    sv.blist_ctr_next = APM_BLIST_CTR(ds.d_work, (ds.sieve_epoch + 1) & 1);
+                    blist_ctr = sv.blist_ctr;
+                }
+                HIP_TRY(ctx, apm_launch_sieve2(sv, ds.n_cu, ds.stream));
+                if (use_blist) ++ds.sieve_epoch; // (a launch that did not run leaves its counter set as it was: still zero)
+                return note_launch(ctx, ds, "sieve");
+            };
+            auto verify_pass = [&](size_t v, int64_t je_v) -> int {
                 VerifyLaunch &V = ctx->sieve.launches[v];
-                const int64_t je_v = std::min<int64_t>(je, nrel - V.m_min + 1);
-                if (je_v <= jb) continue;
                 ApmVerifyArgs va{};
                 va.text = d_text;
                 va.avail = avail;
@@ -1368,9 +1404,9 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 va.code_shift = ctx->sieve.code_shift;
                 va.stride = ctx->sieve.stride;
                 va.masks = ds.d_masks;
-                if (use_blist) {
+                if (blist_ctr) {
                     va.blist = ds.d_blist;
-                    va.blist_ctr = sv.blist_ctr;
+                    va.blist_ctr = blist_ctr;
                 }
                 va.tile0 = p_lo;
                 va.n_mask_blocks = n_mask_blocks;
@@ -1382,8 +1418,31 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 va.work = ds.d_work;
                 if (!V.blocks_per_cu) V.blocks_per_cu = apm_verify_geometry(va, &V.threads);
                 HIP_TRY(ctx, apm_launch_verify(va, V.threads, ds.n_cu * V.blocks_per_cu, &ds.work_epoch, ds.stream));
-                { const int nrc = note_launch(ctx, ds, "verify"); if (nrc) return nrc; }
+                return note_launch(ctx, ds, "verify");
+            };
+            // every launch group with a sieve pass of its own (code filter), when all of them fit a CU in that form ...
+            bool per_launch = ctx->sieve.per_launch_sieve;
+            for (size_t v = 0; per_launch && v < ctx->sieve.launches.size(); ++v) {
+                VerifyLaunch &V = ctx->sieve.launches[v];
+                if (!V.cf_threads) {
+                    V.cf_blocks_per_cu = apm_sieve2cf_geometry((int)V.cf_image.size(), &V.cf_threads);
+                    if (V.cf_blocks_per_cu < 1) V.cf_threads = -1; // does not fit a CU
+                }
+                if (V.cf_threads < 64) per_launch = false;
             }
+            bool any_pass = false;
+            for (size_t v = 0; v < ctx->sieve.launches.size(); ++v) {
+                const int64_t je_v = std::min<int64_t>(je, nrel - ctx->sieve.launches[v].m_min + 1);
+                if (je_v <= jb) continue;
+                if (per_launch || !any_pass) { // ... else ONE pass over the set's shared bitmap, in front of the first verify launch
+                    const int src = sieve_pass(per_launch ? (int)v : -1);
+                    if (src) return src;
+                    any_pass = true;
+                }
+                const int vrc = verify_pass(v, je_v);
+                if (vrc) return vrc;
+            }
+            // (no launch had windows to decide: the tails get their own launch at the end of the call)
             sieve_run = true;
             }
         }
@@ -2352,8 +2411,9 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     if (n == "sieve_on") { *value = ctx->sieve.on ? 1 : 0; return APM_OK; }
     if (n == "sieve_rate") { *value = ctx->sieve.rate; return APM_OK; }
     if (n == "sieve_fused") { *value = ds.last_fused ? 1 : 0; return APM_OK; }
-    if (n == "sieve_cf") { *value = (ctx->sieve.on && !ctx->sieve.cf_image.empty() && ctx->sieve.cf_threads >= 64) ? (double)ctx->sieve.cf_threads : 0.0; return APM_OK; } // (after a call: workgroup size of the code-filter form, 0 = plain sieve)
-    if (n == "sieve_cf_bytes") { *value = (double)ctx->sieve.cf_image.size(); return APM_OK; }
+    if (n == "sieve_cf") { *value = (ctx->sieve.on && ctx->sieve.per_launch_sieve && ctx->sieve.launches[0].cf_threads >= 64) ? (double)ctx->sieve.launches[0].cf_threads : 0.0; return APM_OK; } // (after a call: workgroup size of the code-filter form, 0 = plain sieve)
+    if (n == "sieve_weak_frac") { *value = ctx->sieve.weak_frac; return APM_OK; }
+    if (n == "sieve_cf_bytes") { *value = ctx->sieve.per_launch_sieve ? (double)ctx->sieve.launches[0].cf_image.size() : 0.0; return APM_OK; }
     if (n == "sieve_stride") { *value = ctx->sieve.on ? (double)ctx->sieve.stride : 0.0; return APM_OK; }
     if (n == "sieve_mask_bytes") { *value = (double)ds.last_mask_blocks * 256.0; return APM_OK; }
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }

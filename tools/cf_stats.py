@@ -27,6 +27,6 @@ for name in [a for a in sys.argv[1:]]:
         if best is None or tot < best[0]:
             best = (tot, lt)
     print(name, "APM_SIEVE_CF=%s" % os.environ.get("APM_SIEVE_CF", "1"),
-          {key: ctx.stat(key) for key in ("sieve_rate", "sieve_cf", "sieve_cf_bytes", "sieve_candidates", "verify_image_bytes", "verify_blocks_per_cu", "verify_threads")},
+          {key: ctx.stat(key) for key in ("sieve_rate", "sieve_weak_frac", "sieve_cf", "sieve_cf_bytes", "sieve_candidates", "verify_image_bytes", "verify_blocks_per_cu", "verify_threads")},
           "best of 6: %.4f ms" % best[0], [(l, round(t, 4)) for l, t in best[1]], "sum(counts)=%d" % int(counts.sum().item()))
     del ctx, text

@@ -28,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "worker":
             cnt.zero_(); torch.cuda.synchronize()
             c.count_shard_device(text.data_ptr(), 0, n, n, 0, n, cnt.data_ptr()); c.synchronize()
         lt = c.launch_times()
-        print("P=%d m=%d k=%d APM_SIEVE=%s sieve_on=%d rate=%.4f  %.3f ms per 64 MiB  %s  sum=%d crc=%d" % (P, m, k, os.environ.get("APM_SIEVE", "1"), c.stat("sieve_on"), c.stat("sieve_rate"),
+        print("P=%d m=%d k=%d APM_SIEVE=%s sieve_on=%d rate=%.4f weak=%.2f  %.3f ms per 64 MiB  %s  sum=%d crc=%d" % (P, m, k, os.environ.get("APM_SIEVE", "1"), c.stat("sieve_on"), c.stat("sieve_rate"), c.stat("sieve_weak_frac"),
               sum(t for _, t in lt), [(l, round(t, 3)) for l, t in lt][:6], int(cnt.sum()), int((cnt * torch.arange(1, P + 1, device=cnt.device)).sum() % 1000003)))
 else:
     for P, m, k in ((800, 30, 3), (60, 16, 3), (200, 16, 3), (600, 20, 3), (2000, 50, 5), (1000, 64, 2), (4000, 24, 2)):
