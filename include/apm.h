@@ -67,6 +67,11 @@ typedef enum apm_status {
  *   BANDED     exact for the predicate dist<=k: only diagonals |x-y|<=k/2,
  *              early exit, candidates pre-filtered by pigeonhole sub-keys looked up
  *              in LDS tables (needs m<=512, k<=7, m/(k+1)>=4)
+ *   NFA        exact for the predicate dist<=k, no filter: the k-error automaton over
+ *              the diagonals |x-y|<=k/2, 32 consecutive window starts per lane as
+ *              the bits of a word (needs m + k/2 <= 32, k <= 7, <= 16 distinct
+ *              pattern bytes); AUTO's choice for short patterns with many errors,
+ *              whose pieces are too short for BANDED's filter
  *   GENERIC    literal one-column DP per lane, any m, handles truncated tails
  *   AUTO       fastest applicable exact variant per pattern (default)        */
 typedef enum apm_kernel {
@@ -74,7 +79,8 @@ typedef enum apm_kernel {
     APM_KERNEL_GENERIC = 1,
     APM_KERNEL_WAVEFRONT = 2,
     APM_KERNEL_BITPAR = 3,
-    APM_KERNEL_BANDED = 4
+    APM_KERNEL_BANDED = 4,
+    APM_KERNEL_NFA = 5
 } apm_kernel;
 
 #define APM_MAX_PATTERN_LEN 65535

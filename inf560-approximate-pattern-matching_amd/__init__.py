@@ -18,8 +18,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("APM_LIB_PATH") or os.path.join(_HERE, "libapm_hip.so")  # APM_LIB_PATH: A/B builds
 
-APM_KERNEL_AUTO, APM_KERNEL_GENERIC, APM_KERNEL_WAVEFRONT, APM_KERNEL_BITPAR, APM_KERNEL_BANDED = range(5)
-KERNEL_NAMES = {0: "auto", 1: "generic", 2: "wavefront", 3: "bitpar", 4: "banded"}
+APM_KERNEL_AUTO, APM_KERNEL_GENERIC, APM_KERNEL_WAVEFRONT, APM_KERNEL_BITPAR, APM_KERNEL_BANDED, APM_KERNEL_NFA = range(6)
+KERNEL_NAMES = {0: "auto", 1: "generic", 2: "wavefront", 3: "bitpar", 4: "banded", 5: "nfa"}
 KERNEL_IDS = {v: k for k, v in KERNEL_NAMES.items()}
 
 # every symbol include/apm.h declares (checked by tests/test_abi.py)

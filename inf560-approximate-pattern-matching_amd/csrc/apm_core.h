@@ -193,6 +193,70 @@ APM_HD uint32_t apm_rev_codes(uint32_t w) {
 }
 
 /* ---------------------------------------------------------------------------
+ * The k-error automaton of the window DP over 32 window starts at once (apm_nfa.hip; tests/host_core_test.cpp runs the
+ * same two functions against the literal window DP on the host).  R[e][i]: bit b = "for window start j0 + b, cell(x, x + i - B)
+ * <= e" after x pattern bytes, B = K / 2 (equal lengths: an alignment with <= K edits stays on the diagonals |y - x| <= B).
+ * M[i]: bit b = (text[j0 + b + x + i - B] == pattern[x]).  cell(0, y) = y; cells outside the m x m square are empty; the
+ * window matches iff R[K][B] holds after m bytes.
+ * ------------------------------------------------------------------------- */
+template <int K>
+APM_HD void apm_nfa_init(uint32_t (&R)[K + 1][2 * (K / 2) + 1]) {
+    constexpr int B = K / 2, ND = 2 * B + 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e <= K; ++e)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < ND; ++i) R[e][i] = (i - B >= 0 && i - B <= e) ? 0xffffffffu : 0u;
+}
+/* (a & b) | c and a | b | c in ONE instruction of the 2-cycle class on gfx950 (v_bitop3_b32; the compiler's own choice,
+   v_and_or_b32 / v_or3_b32, issues in 4: tools/valu_probe.hip) */
+APM_HD uint32_t apm_and_or(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xEA);
+#else
+    return (a & b) | c;
+#endif
+}
+APM_HD uint32_t apm_or3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE);
+#else
+    return a | b | c;
+#endif
+}
+/* EDGE: the column has cells outside the square (the first and the last B columns): they are emptied */
+template <int K, bool EDGE>
+APM_HD void apm_nfa_step(const uint32_t (&Rin)[K + 1][2 * (K / 2) + 1], uint32_t (&Rout)[K + 1][2 * (K / 2) + 1],
+                         const uint32_t (&M)[2 * (K / 2) + 1], int x, int m) {
+    constexpr int B = K / 2, ND = 2 * B + 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e <= K; ++e)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < ND; ++i) {
+            uint32_t v;
+            if (e == 0) v = Rin[e][i] & M[i];                                      /* match on the diagonal */
+            else {
+                v = apm_and_or(Rin[e][i], M[i], Rin[e - 1][i]);                     /* ... | substitution */
+                const uint32_t up = i + 1 < ND ? Rin[e - 1][i + 1] : 0u;            /* pattern byte without a text byte (the cell above) */
+                const uint32_t left = i > 0 ? Rout[e - 1][i - 1] : 0u;              /* text byte without a pattern byte (the cell to the left) */
+                if (i + 1 < ND || i > 0) v = apm_or3(v, up, left);
+            }
+            if (EDGE) {
+                const int y = x + 1 + i - B;                                        /* the cell's text offset: inside [0, m] */
+                v = (y >= 0 && y <= m) ? v : 0u;
+            }
+            Rout[e][i] = v;
+        }
+}
+
+/* ---------------------------------------------------------------------------
  * Host side of the presence bitmaps (plan builder in apm_runtime.hip; tests/host_core_test.cpp checks the
  * constructive enumeration against the brute-force definition).
  *

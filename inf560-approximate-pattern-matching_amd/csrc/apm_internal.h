@@ -17,6 +17,7 @@
 #define APM_BANDED_MIN_PIECE 4
 #define APM_BANDED_MAX_K 7
 #define APM_BANDED_MAX_PATS 64
+#define APM_NFA_MAX_K 7          /* apm_nfa.hip: m + k/2 <= 32, <= 16 distinct pattern bytes per launch */
 
 /* Optional sink for match positions (apm_find_buffer): single-pattern launches only. */
 struct ApmPosSink {
@@ -70,6 +71,22 @@ struct ApmGenericArgs {
     int col_stride;        /* m_max + 1 */
     uint16_t *scratch;     /* n_pats * col_stride * (gridDim.x*256) uint16, lane-interleaved */
     unsigned long long *counts;
+    ApmPosSink pos;
+};
+
+/* NFA launch (apm_nfa.hip): short loose patterns, 32 window starts per lane.  Positions relative to text[0]. */
+struct ApmNfaArgs {
+    const uint8_t *text;
+    int64_t avail;
+    int64_t jb, je, nrel;      /* window starts to decide [jb, je); full windows only (truncated ones: the tail kernels) */
+    int64_t tile0;             /* first window start of workgroup 0 (<= jb, text + tile0 16-byte aligned) */
+    const ApmPatDesc *pats;    /* m, byte_off (into classes: a multiple of 32), index */
+    const uint8_t *classes;    /* the patterns as class numbers, 32 bytes each (zero padded), cls_len bytes, 16-byte aligned */
+    int cls_len;
+    uint8_t class_bytes[16];   /* the byte of class c */
+    int n_classes;             /* distinct pattern bytes of the launch, <= 16 */
+    unsigned long long *counts;
+    int n_pats, k;
     ApmPosSink pos;
 };
 
@@ -160,6 +177,8 @@ hipError_t apm_launch_wavefront(const ApmScanArgs &a, hipStream_t s);
 hipError_t apm_launch_generic(const ApmGenericArgs &a, int nbx, int n_pats, hipStream_t s);
 hipError_t apm_launch_synth(uint8_t *dst, uint64_t global_off, uint64_t len, uint64_t seed, hipStream_t s);
 size_t apm_bitpar_lds_bytes(const ApmScanArgs &a);
+/* apm_nfa.hip */
+hipError_t apm_launch_nfa(const ApmNfaArgs &a, hipStream_t s);
 /* apm_bitlong.hip */
 hipError_t apm_launch_bitpar_xwide(const ApmScanArgs &a, unsigned n_tiles, size_t lds_bytes, hipStream_t s); /* 512 < m <= 1024 */
 hipError_t apm_launch_bitlong(const ApmScanArgs &a, int m, hipStream_t s);                                    /* 1024 < m <= 4096, one pattern */

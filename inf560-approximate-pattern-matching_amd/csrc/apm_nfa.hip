@@ -1,0 +1,137 @@
+/*
+ * apm_nfa.hip -- short, loose patterns (m + k/2 <= 32, k <= 7, pieces too short for the BANDED filter): the k-error
+ * automaton of the window DP, evaluated for 32 CONSECUTIVE WINDOW STARTS per lane at once.
+ *
+ * The reference decides dist(p, t[j .. j+m)) <= k per window start j with the full m x m DP
+ * (/root/reference/src/utils.c:76-99 called from /root/reference/src/sequential.c:121-141).  Pattern and window have the
+ * same length, so an alignment with <= k edits has as many insertions as deletions and never leaves the diagonals
+ * |y - x| <= B = k/2.  For each error level e <= k and diagonal d the lane keeps a 32-bit word R[e][d]: bit b says
+ * "for window start j0 + b, cell(x, x + d) <= e" after x pattern bytes.  One pattern byte c advances ALL 32 windows:
+ *
+ *     N[e][d] = (R[e][d] & M_d)            match: t[j + x + d] == c, M_d = T_c >> (x + d), T_c = the positions of byte c
+ *             |  R[e-1][d]                  substitution
+ *             |  R[e-1][d+1]                pattern byte without a text byte (the cell above)
+ *             |  N[e-1][d-1]                text byte without a pattern byte (the cell to the left, same column)
+ *
+ * cells outside the m x m square (y < 0, y > m) are empty; x = 0 starts with cell(0, y) = y; the window matches iff
+ * R[k][0] holds after m bytes.  That is two logic instructions per (e, d) and pattern byte -- (k+1)(2B+1)·2 + 2B+1 shifts
+ * + one LDS read per byte for 32 windows: ~12 instructions per window and pattern at m = 14, k = 3, where the bit-vector
+ * column of BITPAR (one window per lane, 13.7 instructions per column) needs ~190.  T_c, the per-lane bitmask of the text
+ * positions holding byte c (64 positions: 32 window starts + m + B), is built once per lane and launch class (<= 16
+ * distinct pattern bytes per launch) from the text bytes and parked in LDS; every pattern of the launch then reads it.
+ * Exact for the predicate dist <= k (what the reference's `if (distance <= approx_factor)` consumes), not for the distance.
+ */
+#include "apm_internal.h"
+#include "apm_core.h"
+#include "apm_device.h"
+
+#define APM_NFA_TILE (APM_BLOCK * 32) /* window starts per workgroup: 32 per lane */
+
+template <int K>
+__global__ __launch_bounds__(APM_BLOCK) void apm_nfa_kernel(ApmNfaArgs a) {
+    constexpr int B = K / 2, ND = 2 * B + 1, NE = K + 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *s_T = reinterpret_cast<uint32_t *>(smem);                    // [class][word 0 / 1][thread]
+    uint32_t *s_cnt = s_T + (size_t)a.n_classes * 2 * APM_BLOCK;           // [n_pats]
+    uint8_t *s_cls = reinterpret_cast<uint8_t *>(s_cnt + ((a.n_pats + 3) & ~3)); // the patterns as class numbers (a.cls_len bytes)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
+    for (int i = tid; i < a.cls_len / 4; i += APM_BLOCK) reinterpret_cast<uint32_t *>(s_cls)[i] = reinterpret_cast<const uint32_t *>(a.classes)[i];
+
+    // the lane's 64 text bytes: window starts j0 .. j0 + 31 and what their windows reach (m + B <= 32 bytes further)
+    const int64_t j0 = a.tile0 + (int64_t)blockIdx.x * APM_NFA_TILE + (int64_t)tid * 32;
+    uint32_t w[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = apm_load16_guarded(a.text, j0 + 16 * q, a.avail);
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+    // T_c for every class of the launch: bit i of the 64-bit mask = (text[j0 + i] == byte of class c)
+    for (int c = 0; c < a.n_classes; ++c) {
+        const uint32_t cb = (uint32_t)a.class_bytes[c] * 0x01010101u;
+        uint32_t tlo = 0, thi = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t x = w[q] ^ cb;
+            const uint32_t nz = __builtin_amdgcn_udot4(((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7) & 0x01010101u, 0x08040201u, 0u, false); // 4 bits: byte != c
+            const uint32_t eq = nz ^ 0xfu;
+            if (q < 8) tlo |= eq << (4 * q);
+            else thi |= eq << (4 * (q - 8));
+        }
+        s_T[(size_t)(2 * c) * APM_BLOCK + tid] = tlo;
+        s_T[(size_t)(2 * c + 1) * APM_BLOCK + tid] = thi;
+    }
+    __syncthreads(); // (s_cnt; the T words are read by their own lane only)
+
+    // one pattern byte: Rout = the column after it (see the header); Rin is left as it was.  c = its class.
+    auto step = [&](const uint32_t (&Rin)[NE][ND], uint32_t (&Rout)[NE][ND], int x, int m, uint32_t c) __attribute__((always_inline)) {
+        const uint32_t tlo = s_T[(size_t)(2 * c) * APM_BLOCK + tid], thi = s_T[(size_t)(2 * c + 1) * APM_BLOCK + tid];
+        uint32_t M[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int sh = x + i - B; // text offset of pattern byte x on diagonal i - B (< 32)
+            M[i] = sh >= 0 ? __builtin_amdgcn_alignbit(thi, tlo, (uint32_t)sh) : 0u;
+        }
+        if (x + 1 - B < 0 || x + 1 + B > m) apm_nfa_step<K, true>(Rin, Rout, M, x, m); // (wave-uniform: the first / last B columns)
+        else apm_nfa_step<K, false>(Rin, Rout, M, x, m);
+    };
+
+    for (int p = 0; p < a.n_pats; ++p) {
+        const ApmPatDesc d = a.pats[p];
+        const int m = (int)d.m;
+        const uint8_t *cls = s_cls + d.byte_off; // the pattern as class numbers (LDS, one address for the wave)
+        uint32_t R[NE][ND], N[NE][ND];
+        apm_nfa_init<K>(R); // cell(0, y) = y
+        int x = 0;
+        // (two bytes per trip: the columns swap roles instead of being copied, and both class numbers come with one LDS read
+        // -- a scalar after readfirstlane, so the T words' address is the lane's alone.  Fully unrolled over 32 bytes with
+        // scalar class loads the loop measured slower: 9.8 against 8.1 ms per GiB)
+        for (; x + 1 < m; x += 2) {
+            const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint16_t *>(cls + x));
+            step(R, N, x, m, c2 & 0xffu);
+            step(N, R, x + 1, m, c2 >> 8);
+        }
+        if (x < m) step(R, N, x, m, (uint32_t)__builtin_amdgcn_readfirstlane((int)cls[x]));
+        const uint32_t fin = (m & 1) ? N[K][B] : R[K][B];
+        // windows j0 + b that are full windows of this shard's range
+        const int64_t je_p = min(a.je, a.nrel - m + 1);
+        const int64_t lo = a.jb - j0, hi = je_p - j0; // valid bits: [lo, hi)
+        uint32_t valid = 0xffffffffu;
+        if (lo > 0) valid = lo >= 32 ? 0u : (valid << (int)lo);
+        if (hi < 32) valid = hi <= 0 ? 0u : (valid & ((1u << (int)hi) - 1u));
+        uint32_t hits = fin & valid;
+        if (a.pos.out)
+            for (uint32_t h = hits; h; h &= h - 1u) apm_push_pos(a.pos, j0 + (int64_t)__builtin_ctz(h));
+        uint32_t n = (uint32_t)__builtin_popcount(hits);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
+        if ((tid & 63) == 0 && n) atomicAdd(&s_cnt[p], n);
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
+        const uint32_t c = s_cnt[i];
+        if (c) atomicAdd(&a.counts[a.pats[i].index], (unsigned long long)c);
+    }
+}
+
+size_t apm_nfa_lds_bytes(const ApmNfaArgs &a) { return (size_t)a.n_classes * 2 * APM_BLOCK * 4 + (size_t)((a.n_pats + 3) & ~3) * 4 + (size_t)a.cls_len + 16; }
+
+hipError_t apm_launch_nfa(const ApmNfaArgs &a, hipStream_t s) {
+    const int64_t span = a.je - a.tile0;
+    if (span <= 0 || a.n_pats <= 0) return hipSuccess;
+    const int64_t nt = (span + APM_NFA_TILE - 1) / APM_NFA_TILE;
+    if (nt > 0x7fffffffLL || a.k < 0 || a.k > 7 || a.n_classes < 1 || a.n_classes > 16) return hipErrorInvalidValue;
+    const size_t lds = apm_nfa_lds_bytes(a);
+    const dim3 g((unsigned)nt), b(APM_BLOCK);
+    switch (a.k) {
+    case 0: hipLaunchKernelGGL(apm_nfa_kernel<0>, g, b, lds, s, a); break;
+    case 1: hipLaunchKernelGGL(apm_nfa_kernel<1>, g, b, lds, s, a); break;
+    case 2: hipLaunchKernelGGL(apm_nfa_kernel<2>, g, b, lds, s, a); break;
+    case 3: hipLaunchKernelGGL(apm_nfa_kernel<3>, g, b, lds, s, a); break;
+    case 4: hipLaunchKernelGGL(apm_nfa_kernel<4>, g, b, lds, s, a); break;
+    case 5: hipLaunchKernelGGL(apm_nfa_kernel<5>, g, b, lds, s, a); break;
+    case 6: hipLaunchKernelGGL(apm_nfa_kernel<6>, g, b, lds, s, a); break;
+    default: hipLaunchKernelGGL(apm_nfa_kernel<7>, g, b, lds, s, a); break;
+    }
+    return hipGetLastError();
+}

@@ -300,6 +300,7 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
     if (forced == APM_KERNEL_AUTO) {
         if (k >= m) return KERNEL_TRIVIAL;
         if (m <= APM_BANDED_MAX_M && k <= APM_BANDED_MAX_K && m / (k + 1) >= APM_BANDED_MIN_PIECE) return APM_KERNEL_BANDED;
+        if (k <= APM_NFA_MAX_K && m + k / 2 <= 32) return APM_KERNEL_NFA; // short and loose: the automaton over 32 window starts per lane (<= 16 distinct bytes: build_plan)
         if (m <= APM_BITPAR_MAX_M) return APM_KERNEL_BITPAR; // short or loose (BANDED's pigeonhole pieces too short), or long: bit-vector columns
         return APM_KERNEL_GENERIC;                           // m > 4096 only (and long patterns over big alphabets: build_plan)
     }
@@ -311,6 +312,9 @@ int resolve_kernel(int forced, int m, int k, std::string *why) {
     case APM_KERNEL_BITPAR:
         if (m > APM_BITPAR_MAX_M) { *why = "BITPAR kernel supports pattern length <= 4096"; return -100; }
         return APM_KERNEL_BITPAR;
+    case APM_KERNEL_NFA:
+        if (k > APM_NFA_MAX_K || m + k / 2 > 32) { *why = "NFA kernel needs m + k/2 <= 32 and k <= 7"; return -100; }
+        return APM_KERNEL_NFA;
     case APM_KERNEL_BANDED:
         if (m > APM_BANDED_MAX_M || k > APM_BANDED_MAX_K || m / (k + 1) < APM_BANDED_MIN_PIECE) {
             *why = "BANDED kernel needs m <= 512, k <= 7 and m/(k+1) >= 4 (pigeonhole keys of >= 4 bytes)";
@@ -687,6 +691,16 @@ int build_plan(apm_ctx *ctx) {
         std::string why;
         int kv = resolve_kernel(ctx->kernel, ctx->pats[i].m, ctx->k, &why);
         if (kv == -100) return fail(ctx, APM_ERR_UNSUPPORTED, "pattern %d (length %d): %s", i, ctx->pats[i].m, why.c_str());
+        if (kv == APM_KERNEL_NFA) { // every distinct pattern byte is a class of the launch: at most 16
+            bool seen[256] = {false};
+            int nc = 0;
+            for (unsigned char c : ctx->pats[i].bytes) if (!seen[c]) { seen[c] = true; ++nc; }
+            if (nc > 16) {
+                if (ctx->kernel == APM_KERNEL_NFA)
+                    return fail(ctx, APM_ERR_UNSUPPORTED, "pattern %d (length %d): NFA kernel takes at most 16 distinct pattern bytes", i, ctx->pats[i].m);
+                kv = APM_KERNEL_BITPAR;
+            }
+        }
         if (kv == APM_KERNEL_BITPAR && ctx->pats[i].m > 1024) {
             // one window per wave: the pattern's Eq rows (64 or 128 words per distinct byte, + the "absent" row) must fit LDS
             bool seen[256] = {false};
@@ -707,6 +721,16 @@ int build_plan(apm_ctx *ctx) {
         d.m = (uint32_t)ctx->pats[i].m;
         d.byte_off = raw_off[i];
         d.index = (uint32_t)i;
+        if (kv == APM_KERNEL_NFA) { // every distinct pattern byte is a class of the launch: at most 16
+            bool seen[256] = {false};
+            int nc = 0;
+            for (unsigned char c : ctx->pats[i].bytes) if (!seen[c]) { seen[c] = true; ++nc; }
+            if (nc > 16) {
+                if (ctx->kernel == APM_KERNEL_NFA)
+                    return fail(ctx, APM_ERR_UNSUPPORTED, "pattern %d (length %d): NFA kernel takes at most 16 distinct pattern bytes", i, ctx->pats[i].m);
+                kv = APM_KERNEL_BITPAR;
+            }
+        }
         if (kv == APM_KERNEL_BITPAR && ctx->pats[i].m > 1024) {
             // (the one-window-per-wave kernel evaluates its truncated windows itself)
         } else if (kv != APM_KERNEL_GENERIC) { // GENERIC scans truncated windows itself (mode 2)
@@ -784,6 +808,38 @@ int build_plan(apm_ctx *ctx) {
                 L.m_max = std::max(L.m_max, pi.m);
                 L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
             }
+            ctx->tiled.push_back(std::move(L));
+        }
+    }
+    // ---- NFA launches: <= 16 byte classes, <= 512 patterns and 16 KiB of class numbers per launch ----
+    {
+        std::vector<int> idx;
+        for (int i = 0; i < P; ++i) if (ctx->pats[i].kernel == APM_KERNEL_NFA) idx.push_back(i);
+        for (size_t pos = 0; pos < idx.size();) {
+            TiledLaunch L;
+            L.kind = APM_KERNEL_NFA;
+            memset(L.lut, 0, sizeof L.lut);
+            int cls_of[256];
+            for (int c = 0; c < 256; ++c) cls_of[c] = -1;
+            int nc = 0;
+            for (; pos < idx.size() && L.descs.size() < 512; ++pos) {
+                const PatternInfo &pi = ctx->pats[idx[pos]];
+                int add = 0;
+                bool seen[256] = {false};
+                for (unsigned char c : pi.bytes) if (cls_of[c] < 0 && !seen[c]) { seen[c] = true; ++add; }
+                if (!L.descs.empty() && nc + add > 16) break;
+                for (unsigned char c : pi.bytes) if (cls_of[c] < 0) { cls_of[c] = nc; L.lut[nc++] = c; }
+                ApmPatDesc d{};
+                d.m = (uint32_t)pi.m;
+                d.index = (uint32_t)idx[pos];
+                d.byte_off = (uint32_t)L.bytes.size();
+                for (unsigned char c : pi.bytes) L.bytes.push_back((uint8_t)cls_of[c]);
+                while (L.bytes.size() % 32) L.bytes.push_back(0); // (32 bytes per pattern: the kernel reads them with two scalar 16-byte loads)
+                L.descs.push_back(d);
+                L.m_max = std::max(L.m_max, pi.m);
+                L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
+            }
+            L.nb = nc; // classes; their bytes: lut[0 .. nc)
             ctx->tiled.push_back(std::move(L));
         }
     }
@@ -1562,6 +1618,27 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
             { const int nrc = note_launch(ctx, ds, "tile"); if (nrc) return nrc; }
             continue;
         }
+        if (L.kind == APM_KERNEL_NFA) {
+            ApmNfaArgs na{};
+            na.text = d_text;
+            na.avail = avail;
+            na.jb = jb;
+            na.je = je_l;
+            na.nrel = nrel;
+            na.tile0 = jb - (int64_t)((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)jb) & 15u);
+            na.pats = ds.tiled[t].d_descs;
+            na.classes = ds.tiled[t].d_bytes;
+            na.cls_len = (int)L.bytes.size();
+            memcpy(na.class_bytes, L.lut, 16);
+            na.n_classes = L.nb;
+            na.counts = d_counts;
+            na.n_pats = (int)L.descs.size();
+            na.k = ctx->k;
+            na.pos = sink;
+            HIP_TRY(ctx, apm_launch_nfa(na, ds.stream));
+            { const int nrc = note_launch(ctx, ds, "nfa"); if (nrc) return nrc; }
+            continue;
+        }
         ApmScanArgs a{};
         a.text = d_text;
         a.avail = avail;
@@ -1652,7 +1729,7 @@ void account(apm_ctx *ctx, uint64_t n_total, uint64_t ob, uint64_t oe) {
         }
         ctx->timing.windows += oe - ob;
         ctx->timing.cells_algorithmic += cells;
-        if (p.kernel == APM_KERNEL_BANDED)
+        if (p.kernel == APM_KERNEL_BANDED || p.kernel == APM_KERNEL_NFA)
             ctx->timing.cells_evaluated += double(oe - ob) * double(m) * double(2 * (ctx->k / 2) + 1); // upper bound
         else if (p.kernel != KERNEL_TRIVIAL)
             ctx->timing.cells_evaluated += cells;
@@ -2161,7 +2238,7 @@ int apm_set_timing(apm_ctx *ctx, int enabled) {
 
 int apm_set_kernel(apm_ctx *ctx, int kernel) {
     if (!ctx) return APM_ERR_INVALID;
-    if (kernel < APM_KERNEL_AUTO || kernel > APM_KERNEL_BANDED) return fail(ctx, APM_ERR_INVALID, "unknown kernel variant %d", kernel);
+    if (kernel < APM_KERNEL_AUTO || kernel > APM_KERNEL_NFA) return fail(ctx, APM_ERR_INVALID, "unknown kernel variant %d", kernel);
     const int old = ctx->kernel;
     ctx->kernel = kernel;
     if (ctx->patterns_set || !ctx->pats.empty()) {

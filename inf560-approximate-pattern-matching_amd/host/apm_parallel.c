@@ -34,6 +34,7 @@ static int kernel_by_name(const char *s) {
     if (!strcmp(s, "wavefront")) return APM_KERNEL_WAVEFRONT;
     if (!strcmp(s, "bitpar")) return APM_KERNEL_BITPAR;
     if (!strcmp(s, "banded")) return APM_KERNEL_BANDED;
+    if (!strcmp(s, "nfa")) return APM_KERNEL_NFA;
     return -1;
 }
 

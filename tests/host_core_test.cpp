@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 template <int W>
@@ -265,6 +266,53 @@ int main() {
             }
         }
         if (pos < 100000 || rejected < 10000) { printf("code filter test saw too few cases (%ld positives, %ld exact negatives, %ld rejected)\n", pos, neg_exact, rejected); bad++; }
+    }
+    // the k-error automaton over 32 window starts (apm_core.h, apm_nfa_init / apm_nfa_step: the kernel of apm_nfa.hip runs the
+    // same two functions): bit b of R[K][B] after m bytes == (oracle window distance of start j0 + b <= K)
+    {
+        long checked = 0, positives = 0;
+        auto run = [&](auto kc, const unsigned char *pat, int m, const unsigned char *text /* 64 bytes */) -> uint32_t {
+            constexpr int K = decltype(kc)::value, B = K / 2, ND = 2 * B + 1;
+            uint32_t R[K + 1][ND], N[K + 1][ND];
+            apm_nfa_init<K>(R);
+            for (int x = 0; x < m; ++x) {
+                uint64_t T = 0;
+                for (int i = 0; i < 64; ++i) T |= (uint64_t)(text[i] == pat[x]) << i;
+                uint32_t M[ND];
+                for (int i = 0; i < ND; ++i) { const int sh = x + i - B; M[i] = sh >= 0 ? (uint32_t)(T >> sh) : 0u; }
+                if (x + 1 - B < 0 || x + 1 + B > m) apm_nfa_step<K, true>(R, N, M, x, m); else apm_nfa_step<K, false>(R, N, M, x, m);
+                memcpy(R, N, sizeof R);
+            }
+            return R[K][B];
+        };
+        for (int it = 0; it < 60000; it++) {
+            const int k = rand() % 8, B = k / 2;
+            const int m = 1 + rand() % (32 - B);
+            const int alpha = 2 + rand() % 3;
+            unsigned char text[64 + 40], pat[32];
+            for (int i = 0; i < 104; i++) text[i] = (unsigned char)('a' + rand() % alpha);
+            const int o = rand() % 32;
+            for (int i = 0; i < m; i++) pat[i] = (rand() % 5) ? text[o + i] : (unsigned char)('a' + rand() % alpha);
+            if (rand() % 3 == 0 && m > 2) { memmove(pat + 1, pat, (size_t)m - 1); pat[0] = (unsigned char)('a' + rand() % alpha); } // an indel pair
+            uint32_t got;
+            switch (k) {
+            case 0: got = run(std::integral_constant<int, 0>(), pat, m, text); break;
+            case 1: got = run(std::integral_constant<int, 1>(), pat, m, text); break;
+            case 2: got = run(std::integral_constant<int, 2>(), pat, m, text); break;
+            case 3: got = run(std::integral_constant<int, 3>(), pat, m, text); break;
+            case 4: got = run(std::integral_constant<int, 4>(), pat, m, text); break;
+            case 5: got = run(std::integral_constant<int, 5>(), pat, m, text); break;
+            case 6: got = run(std::integral_constant<int, 6>(), pat, m, text); break;
+            default: got = run(std::integral_constant<int, 7>(), pat, m, text); break;
+            }
+            for (int b = 0; b < 32; b++) {
+                const bool want = oracle_window_distance(pat, text + b, m, col.data()) <= k;
+                checked++;
+                positives += want;
+                if (want != (bool)((got >> b) & 1u)) { bad++; if (bad < 5) printf("nfa m=%d k=%d start %d: got %d want %d\n", m, k, b, (int)((got >> b) & 1u), (int)want); }
+            }
+        }
+        if (positives < 20000 || checked - positives < 20000) { printf("nfa test saw too few cases (%ld of %ld positive)\n", positives, checked); bad++; }
     }
     // synthetic generator: bytes are ACGT, deterministic
     for (uint64_t i = 0; i < 1000; i++) {

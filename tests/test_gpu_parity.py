@@ -14,16 +14,21 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = ["auto", "banded", "bitpar", "wavefront", "generic"]
-MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 4096, "wavefront": 256, "banded": 512}
+VARIANTS = ["auto", "banded", "bitpar", "wavefront", "generic", "nfa"]
+MAX_M = {"auto": 65535, "generic": 65535, "bitpar": 4096, "wavefront": 256, "banded": 512, "nfa": 32}
 
 
 def _supported(variant, m, k):
-    """mirror of the library's documented limits (include/apm.h, apm_set_kernel -> UNSUPPORTED)"""
+    """mirror of the library's documented limits (include/apm.h, apm_set_kernel -> UNSUPPORTED); m: a length or the pattern"""
+    pat = None
+    if isinstance(m, (bytes, bytearray)):
+        pat, m = m, len(m)
     if m > MAX_M[variant]:
         return False
     if variant == "banded":
         return k <= 7 and m // (k + 1) >= 4
+    if variant == "nfa":
+        return k <= 7 and m + k // 2 <= 32 and (pat is None or len(set(pat)) <= 16)
     return True
 
 CASES = H.golden()["cases"]
@@ -54,7 +59,7 @@ def _run(ctx, apm, variant, patterns, k, text):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_golden(ctx, apm, case, variant):
     pats, k = case["patterns"], case["k"]
-    if not all(_supported(variant, len(p), k) for p in pats):
+    if not all(_supported(variant, p, k) for p in pats):
         ctx.set_kernel("auto")
         ctx.set_patterns(pats, k)
         with pytest.raises(apm.ApmError) as e:      # error behaviour: UNSUPPORTED, state unchanged
@@ -109,7 +114,7 @@ def test_random_vs_oracle(ctx, apm, variant):
                 p = bytes(rnd.choice(alpha) for _ in range(m))
             pats.append(p)
         k = rnd.choice([0, 0, 1, 2, 3, 4, 5, 6, 9])
-        pats = [p for p in pats if _supported(variant, len(p), k)]
+        pats = [p for p in pats if _supported(variant, p, k)]
         if not pats:
             continue
         want = H.oracle_counts(text, pats, k)
@@ -252,7 +257,7 @@ def test_baseline_workloads_small_vs_oracle(ctx, apm, cfg):
     for (o, d), w in zip(planted, want):
         assert (w >= 1) or d > c["k"]
     for variant in ("auto", "banded", "bitpar", "wavefront"):
-        sub = [i for i, p in enumerate(pats) if _supported(variant, len(p), c["k"])]
+        sub = [i for i, p in enumerate(pats) if _supported(variant, p, c["k"])]
         assert sub
         ctx.set_kernel("auto")
         ctx.set_patterns([pats[i] for i in sub], c["k"])
@@ -529,6 +534,72 @@ def test_long_patterns_over_bigger_alphabets(ctx, apm, m, k, alphabet):
     ctx.set_kernel("auto")
 
 
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"ab", b"ACGTN\n", bytes(range(65, 81))])
+def test_short_loose_patterns_through_the_automaton(ctx, apm, alphabet):
+    """Short patterns with many errors (pieces too short for BANDED's filter): AUTO routes them to the k-error automaton
+    over 32 window starts per lane (apm_nfa.hip).  Every (m, k) with m + k/2 <= 32, k <= 7 and m / (k+1) < 4 on texts
+    with planted edited occurrences, shard cuts at odd offsets, text shorter than a lane's 64 bytes: AUTO == forced NFA ==
+    forced BITPAR == the CPU oracle."""
+    import torch
+    rnd = random.Random(len(alphabet) * 7919)
+    n = 70000
+    text = bytearray(rnd.choice(alphabet) for _ in range(n))
+    sets = {}
+    for k in range(0, 8):
+        for m in range(1, 33):
+            if m + k // 2 > 32 or m // (k + 1) >= 4 or k >= m:
+                continue
+            if rnd.random() > (1.0 if m in (1, 2, 3, 12, 15, 28, 29) or k in (0, 7) else 0.25):
+                continue
+            o = rnd.randrange(0, n - m)
+            p = bytearray(text[o:o + m])
+            for _e in range(rnd.randrange(0, k + 1)):
+                r, pos = rnd.random(), rnd.randrange(len(p))
+                if r < 0.5:
+                    p[pos] = rnd.choice(alphabet)
+                elif r < 0.75 and len(p) > 1:
+                    del p[pos]
+                    p.append(rnd.choice(alphabet))
+                else:
+                    p.insert(pos, rnd.choice(alphabet))
+                    p.pop()
+            sets.setdefault(k, []).append(bytes(p))
+    text = bytes(text)
+    assert len(sets) == 8
+    for k, pats in sorted(sets.items()):
+        want = H.oracle_counts(text, pats, k)
+        ctx.set_kernel("auto")
+        ctx.set_patterns(pats, k)
+        assert all(ctx.pattern_kernel(i) == 5 for i in range(len(pats))), k
+        assert ctx.count_buffer(text) == want, ("auto", k)
+        for variant in ("nfa", "bitpar"):
+            ctx.set_kernel(variant)
+            assert ctx.count_buffer(text) == want, (variant, k)
+        ctx.set_kernel("auto")
+        assert ctx.count_buffer(text[:37]) == H.oracle_counts(text[:37], pats, k), ("short text", k)
+        # owner ranges cut at odd places, device text at an unaligned address
+        t = torch.empty(n + 64, dtype=torch.uint8, device="cuda:0")
+        t[3:3 + n] = torch.frombuffer(bytearray(text), dtype=torch.uint8).to("cuda:0")
+        cnt = torch.zeros(len(pats), dtype=torch.int64, device="cuda:0")
+        m_max = max(len(p) for p in pats)
+        total = [0] * len(pats)
+        cuts = [0, 1, 33, 4097, 40001, n]
+        for ob, oe in zip(cuts[:-1], cuts[1:]):
+            hi = min(n, oe + m_max - 1)
+            cnt.zero_()
+            torch.cuda.synchronize()
+            ctx.count_shard_device(t.data_ptr() + 3 + ob, ob, hi - ob, n, ob, oe, cnt.data_ptr())
+            ctx.synchronize()
+            total = [a + b for a, b in zip(total, cnt.cpu().tolist())]
+        assert total == want, ("shards", k)
+    ctx.set_kernel("auto")
+    ctx.set_patterns([bytes(range(40, 60))], 5)           # 20 distinct bytes: no automaton
+    assert ctx.pattern_kernel(0) == 3
+    with pytest.raises(apm.ApmError):
+        ctx.set_kernel("nfa")
+    ctx.set_kernel("auto")
+
+
 def test_reference_gpu_entry_points_link_level(tmp_path):
     """include/apm_refshim.h: a C program calls getDeviceCount/setDevice, invoke_kernel/write_kernel_result and
     initializeGPU/getGPUResult exactly as the reference's host files do, linked against libapm_hip.so only."""
@@ -617,7 +688,7 @@ def test_low_entropy_text_every_window_is_a_candidate(ctx, apm, variant):
     for text in texts:
         for k in (0, 1, 2, 3, 5):
             pats = [text[100:100 + m] for m in (24, 32, 50, 64, 128)] + [b"A" * 31 + b"C", b"C" + b"A" * 40]
-            pats = [p for p in pats if _supported(variant, len(p), k)]
+            pats = [p for p in pats if _supported(variant, p, k)]
             want = H.oracle_counts(text, pats, k, banded=True)
             assert _run(ctx, apm, variant, pats, k, text) == want, (len(text), k)
 
@@ -910,7 +981,7 @@ def test_repeated_pieces_and_identical_patterns(ctx, apm, variant):
     for text in texts:
         for k in (0, 1, 2, 3, 5, 7):
             pats = [unit * 4, unit * 4, unit * 8, (unit * 8)[3:35], unit * 16, unit * 32]
-            pats = [p for p in pats if _supported(variant, len(p), k)]
+            pats = [p for p in pats if _supported(variant, p, k)]
             want = H.oracle_counts(text, pats, k, banded=True)
             assert _run(ctx, apm, variant, pats, k, text) == want, (k, [len(p) for p in pats])
 
@@ -1077,7 +1148,8 @@ def test_every_filter_kernel_form_agrees_with_oracle(env):
             assert res["stride"] == 8 and res["fused"] == (0 if env.get("APM_FUSED") == "0" else 1), (key, env, res["stride"], res["fused"])
         pats = [p.encode("latin-1") for p in res["patterns"]]
         for p, kern in zip(pats, res["kernels"]):
-            assert kern == (4 if len(p) // (int(k) + 1) >= 4 else 3), "BANDED wherever the pieces are long enough"
+            want_kern = 4 if len(p) // (int(k) + 1) >= 4 else (5 if int(k) <= 7 and len(p) + int(k) // 2 <= 32 and len(set(p)) <= 16 else 3)
+            assert kern == want_kern, "BANDED wherever the pieces are long enough, the automaton for short loose patterns, else the bit-vector kernel"
         assert res["counts"] == H.oracle_counts(texts[name], pats, int(k), banded=True), (key, env)
         assert sum(res["counts"]) >= (4 if key.endswith(":long") else 5)
 
@@ -1372,7 +1444,7 @@ def test_all_kernels_soak_vs_oracle(ctx, apm, seed):
                     p.insert(pos, rnd.choice(alpha))
                     p.pop()
             pats.append(bytes(p))
-        pats = [p for p in pats if _supported(variant, len(p), k)]
+        pats = [p for p in pats if _supported(variant, p, k)]
         if not pats:
             continue
         want = H.oracle_counts(text, pats, k, banded=True)
