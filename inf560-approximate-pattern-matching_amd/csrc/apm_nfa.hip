@@ -85,7 +85,8 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_nfa_kernel(ApmNfaArgs a) {
         int x = 0;
         // (two bytes per trip: the columns swap roles instead of being copied, and both class numbers come with one LDS read
         // -- a scalar after readfirstlane, so the T words' address is the lane's alone.  Fully unrolled over 32 bytes with
-        // scalar class loads the loop measured slower: 9.8 against 8.1 ms per GiB)
+        // scalar class loads the loop measured slower, 9.8 against 9.0 ms per GiB, and so did T words kept in registers
+        // for <= 4 classes, picked by uniform selects: 10.9)
         for (; x + 1 < m; x += 2) {
             const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint16_t *>(cls + x));
             step(R, N, x, m, c2 & 0xffu);
@@ -102,10 +103,7 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_nfa_kernel(ApmNfaArgs a) {
         uint32_t hits = fin & valid;
         if (a.pos.out)
             for (uint32_t h = hits; h; h &= h - 1u) apm_push_pos(a.pos, j0 + (int64_t)__builtin_ctz(h));
-        uint32_t n = (uint32_t)__builtin_popcount(hits);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o, 64);
-        if ((tid & 63) == 0 && n) atomicAdd(&s_cnt[p], n);
+        if (hits) atomicAdd(&s_cnt[p], (uint32_t)__builtin_popcount(hits)); // (matches are rare: a handful of lanes, one LDS atomic)
     }
     __syncthreads();
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) {
