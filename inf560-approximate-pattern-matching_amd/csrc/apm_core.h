@@ -199,6 +199,10 @@ APM_HD uint32_t apm_rev_codes(uint32_t w) {
  * M[i]: bit b = (text[j0 + b + x + i - B] == pattern[x]).  cell(0, y) = y; cells outside the m x m square are empty; the
  * window matches iff R[K][B] holds after m bytes.
  * ------------------------------------------------------------------------- */
+/* The cells that can lie on a path to the accepting cell (K, 0): reaching diagonal d costs |d| errors and so does coming
+   back from it -- |d| <= e and e + |d| <= K.  The others are never set (|d| > e) or never used (e + |d| > K); kept at a
+   constant 0 they cost nothing: 8 of 12 cells at K = 3, 32 of 56 at K = 7. */
+APM_HD constexpr bool apm_nfa_live(int K, int e, int d) { return (d < 0 ? -d : d) <= e && e + (d < 0 ? -d : d) <= K; }
 template <int K>
 APM_HD void apm_nfa_init(uint32_t (&R)[K + 1][2 * (K / 2) + 1]) {
     constexpr int B = K / 2, ND = 2 * B + 1;
@@ -209,7 +213,7 @@ APM_HD void apm_nfa_init(uint32_t (&R)[K + 1][2 * (K / 2) + 1]) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int i = 0; i < ND; ++i) R[e][i] = (i - B >= 0 && i - B <= e) ? 0xffffffffu : 0u;
+        for (int i = 0; i < ND; ++i) R[e][i] = (i - B >= 0 && i - B <= e && apm_nfa_live(K, e, i - B)) ? 0xffffffffu : 0u;
 }
 /* (a & b) | c and a | b | c in ONE instruction of the 2-cycle class on gfx950 (v_bitop3_b32; the compiler's own choice,
    v_and_or_b32 / v_or3_b32, issues in 4: tools/valu_probe.hip) */
@@ -241,12 +245,20 @@ APM_HD void apm_nfa_step(const uint32_t (&Rin)[K + 1][2 * (K / 2) + 1], uint32_t
 #endif
         for (int i = 0; i < ND; ++i) {
             uint32_t v;
+            if (!apm_nfa_live(K, e, i - B)) {
+                Rout[e][i] = 0u;
+                continue;
+            }
             if (e == 0) v = Rin[e][i] & M[i];                                      /* match on the diagonal */
             else {
-                v = apm_and_or(Rin[e][i], M[i], Rin[e - 1][i]);                     /* ... | substitution */
-                const uint32_t up = i + 1 < ND ? Rin[e - 1][i + 1] : 0u;            /* pattern byte without a text byte (the cell above) */
-                const uint32_t left = i > 0 ? Rout[e - 1][i - 1] : 0u;              /* text byte without a pattern byte (the cell to the left) */
-                if (i + 1 < ND || i > 0) v = apm_or3(v, up, left);
+                const bool has_sub = apm_nfa_live(K, e - 1, i - B);
+                const bool has_up = i + 1 < ND && apm_nfa_live(K, e - 1, i + 1 - B), has_left = i > 0 && apm_nfa_live(K, e - 1, i - 1 - B);
+                v = has_sub ? apm_and_or(Rin[e][i], M[i], Rin[e - 1][i])            /* ... | substitution */
+                            : (Rin[e][i] & M[i]);
+                const uint32_t up = has_up ? Rin[e - 1][i + 1] : 0u;                /* pattern byte without a text byte (the cell above) */
+                const uint32_t left = has_left ? Rout[e - 1][i - 1] : 0u;           /* text byte without a pattern byte (the cell to the left) */
+                if (has_up && has_left) v = apm_or3(v, up, left);
+                else if (has_up || has_left) v |= up | left;
             }
             if (EDGE) {
                 const int y = x + 1 + i - B;                                        /* the cell's text offset: inside [0, m] */

@@ -1136,8 +1136,11 @@ hipError_t apm_launch_verify(const ApmVerifyArgs &a, int threads, int max_blocks
 // ---------------------------------------------------------------------------
 // FUSED: sieve + verify in one launch (apm_verify_body<.., FUSED = true>; see ApmFusedArgs)
 // ---------------------------------------------------------------------------
+#ifndef APM_FUSED_S_WAVES
+#define APM_FUSED_S_WAVES 6 /* waves per SIMD the sampled fused form with band 1 is compiled for (80 registers; 5: 86 registers, cfg4 0.205 -> 0.198 ms; 7 and 8 fit only without the prefetch and measured 0.200 / 0.210: profiles/r03/cfg4_ab.txt) */
+#endif
 template <int BAND, bool SAMPLED>
-__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND == 0 ? 7 : 5) : (BAND == 0 ? 6 : 5)) void apm_fused_kernel(ApmFusedArgs f) {
+__global__ __launch_bounds__(APM_FUSED_MAX_THREADS, SAMPLED ? (BAND == 0 ? 7 : (BAND == 1 ? APM_FUSED_S_WAVES : 5)) : (BAND == 0 ? 6 : 5)) void apm_fused_kernel(ApmFusedArgs f) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     if ((int)blockIdx.x >= f.s.n_main_blocks) { // extra workgroups: truncated tail windows (one pattern each)
         apm_tail_body(f.s.tail, (int)blockIdx.x - f.s.n_main_blocks, reinterpret_cast<uint4 *>(smem), (int)threadIdx.x);
