@@ -251,14 +251,19 @@ APM_HD void apm_nfa_step(const uint32_t (&Rin)[K + 1][2 * (K / 2) + 1], uint32_t
             }
             if (e == 0) v = Rin[e][i] & M[i];                                      /* match on the diagonal */
             else {
+                /* the live ones among: substitution, the cell above (pattern byte without a text byte), the cell to the left
+                   (text byte without a pattern byte, same column); explicit three-input forms -- left to itself the compiler
+                   picks v_and_or_b32, which issues at half the rate of v_bitop3_b32 */
                 const bool has_sub = apm_nfa_live(K, e - 1, i - B);
                 const bool has_up = i + 1 < ND && apm_nfa_live(K, e - 1, i + 1 - B), has_left = i > 0 && apm_nfa_live(K, e - 1, i - 1 - B);
-                v = has_sub ? apm_and_or(Rin[e][i], M[i], Rin[e - 1][i])            /* ... | substitution */
-                            : (Rin[e][i] & M[i]);
-                const uint32_t up = has_up ? Rin[e - 1][i + 1] : 0u;                /* pattern byte without a text byte (the cell above) */
-                const uint32_t left = has_left ? Rout[e - 1][i - 1] : 0u;           /* text byte without a pattern byte (the cell to the left) */
-                if (has_up && has_left) v = apm_or3(v, up, left);
-                else if (has_up || has_left) v |= up | left;
+                uint32_t o[3] = {0u, 0u, 0u};
+                int n = 0;
+                if (has_sub) o[n++] = Rin[e - 1][i];
+                if (has_up) o[n++] = Rin[e - 1][i + 1];
+                if (has_left) o[n++] = Rout[e - 1][i - 1];
+                v = n == 0 ? (Rin[e][i] & M[i]) : apm_and_or(Rin[e][i], M[i], o[0]);
+                if (n == 2) v |= o[1];
+                else if (n == 3) v = apm_or3(v, o[1], o[2]);
             }
             if (EDGE) {
                 const int y = x + 1 + i - B;                                        /* the cell's text offset: inside [0, m] */

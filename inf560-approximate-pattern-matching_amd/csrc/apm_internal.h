@@ -80,8 +80,8 @@ struct ApmNfaArgs {
     int64_t avail;
     int64_t jb, je, nrel;      /* window starts to decide [jb, je); full windows only (truncated ones: the tail kernels) */
     int64_t tile0;             /* first window start of workgroup 0 (<= jb, text + tile0 16-byte aligned) */
-    const ApmPatDesc *pats;    /* m, byte_off (into classes: a multiple of 32), index */
-    const uint8_t *classes;    /* the patterns as class numbers, 32 bytes each (zero padded), cls_len bytes, 16-byte aligned */
+    const ApmPatDesc *pats;    /* m, byte_off (into classes: a multiple of 16), index */
+    const uint8_t *classes;    /* the patterns as class numbers, one nibble per pattern byte, 16 bytes each (zero padded), cls_len bytes, 16-byte aligned */
     int cls_len;
     uint8_t class_bytes[16];   /* the byte of class c */
     int n_classes;             /* distinct pattern bytes of the launch, <= 16 */

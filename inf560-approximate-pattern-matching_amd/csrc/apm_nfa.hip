@@ -14,11 +14,15 @@
  *             |  N[e-1][d-1]                text byte without a pattern byte (the cell to the left, same column)
  *
  * cells outside the m x m square (y < 0, y > m) are empty; x = 0 starts with cell(0, y) = y; the window matches iff
- * R[k][0] holds after m bytes.  That is two logic instructions per (e, d) and pattern byte -- (k+1)(2B+1)·2 + 2B+1 shifts
- * + one LDS read per byte for 32 windows: ~12 instructions per window and pattern at m = 14, k = 3, where the bit-vector
- * column of BITPAR (one window per lane, 13.7 instructions per column) needs ~190.  T_c, the per-lane bitmask of the text
- * positions holding byte c (64 positions: 32 window starts + m + B), is built once per lane and launch class (<= 16
- * distinct pattern bytes per launch) from the text bytes and parked in LDS; every pattern of the launch then reads it.
+ * R[k][0] holds after m bytes.  Only the cells that can lie on a path to the accepting one are kept -- |d| <= e and
+ * e + |d| <= k (apm_nfa_live): 8 of the 12 at k = 3, 32 of 56 at k = 7 -- each one or two three-input logic instructions
+ * (v_bitop3_b32, the 2-cycle class), plus 2B+1 funnel shifts, one LDS read and one address add per pattern byte for 32
+ * windows: 12 + 3 + 2 instructions per byte at k = 3, ~8 per window and pattern at m = 14, where the bit-vector column of
+ * BITPAR (one window per lane, 13.7 instructions per column) needs ~190.  T_c, the per-lane bitmask of the text positions
+ * holding byte c (64 positions: 32 window starts + m + B), is built once per lane and launch class (<= 16 distinct
+ * pattern bytes per launch) from the text bytes and parked in LDS; every pattern of the launch then reads it.  The
+ * pattern itself is a string of class numbers, a nibble per byte, that stays on the scalar unit (one 16-byte scalar
+ * load per pattern, a 64-bit shift per two columns).
  * Exact for the predicate dist <= k (what the reference's `if (distance <= approx_factor)` consumes), not for the distance.
  */
 #include "apm_internal.h"
@@ -33,10 +37,8 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_nfa_kernel(ApmNfaArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *s_T = reinterpret_cast<uint32_t *>(smem);                    // [class][word 0 / 1][thread]
     uint32_t *s_cnt = s_T + (size_t)a.n_classes * 2 * APM_BLOCK;           // [n_pats]
-    uint8_t *s_cls = reinterpret_cast<uint8_t *>(s_cnt + ((a.n_pats + 3) & ~3)); // the patterns as class numbers (a.cls_len bytes)
     const int tid = threadIdx.x;
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
-    for (int i = tid; i < a.cls_len / 4; i += APM_BLOCK) reinterpret_cast<uint32_t *>(s_cls)[i] = reinterpret_cast<const uint32_t *>(a.classes)[i];
 
     // the lane's 64 text bytes: window starts j0 .. j0 + 31 and what their windows reach (m + B <= 32 bytes further)
     const int64_t j0 = a.tile0 + (int64_t)blockIdx.x * APM_NFA_TILE + (int64_t)tid * 32;
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_nfa_kernel(ApmNfaArgs a) {
 
     // one pattern byte: Rout = the column after it (see the header); Rin is left as it was.  c = its class.
     auto step = [&](const uint32_t (&Rin)[NE][ND], uint32_t (&Rout)[NE][ND], int x, int m, uint32_t c) __attribute__((always_inline)) {
-        const uint32_t tlo = s_T[(size_t)(2 * c) * APM_BLOCK + tid], thi = s_T[(size_t)(2 * c + 1) * APM_BLOCK + tid];
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(c * 2u * APM_BLOCK)); // (kept on the scalar unit: one v_add for the address)
+        const uint32_t tlo = s_T[base + (uint32_t)tid], thi = s_T[base + APM_BLOCK + (uint32_t)tid];
         uint32_t M[ND];
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
@@ -76,30 +79,37 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_nfa_kernel(ApmNfaArgs a) {
         else apm_nfa_step<K, false>(Rin, Rout, M, x, m);
     };
 
+    // the lane's window starts against the range [jb, min(je, nrel - m + 1)), clamped once to what 32 bits hold
+    const int64_t lo64 = a.jb - j0, je64 = a.je - j0, end64 = a.nrel + 1 - j0;
+    const uint32_t lo_mask = lo64 <= 0 ? 0xffffffffu : (lo64 >= 32 ? 0u : (0xffffffffu << (int)lo64));
+    const int je_rel = (int)(je64 < -64 ? -64 : (je64 > 64 ? 64 : je64)), end_rel = (int)(end64 < -64 ? -64 : (end64 > 128 ? 128 : end64));
     for (int p = 0; p < a.n_pats; ++p) {
         const ApmPatDesc d = a.pats[p];
         const int m = (int)d.m;
-        const uint8_t *cls = s_cls + d.byte_off; // the pattern as class numbers (LDS, one address for the wave)
+        // the pattern as class numbers, a nibble per byte: one scalar 16-byte load, the next class shifted out per column --
+        // no LDS read in front of the T words' address
+        const uint4 cw = *reinterpret_cast<const uint4 *>(a.classes + d.byte_off);
+        unsigned long long clo = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)cw.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cw.x);
+        unsigned long long chi = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)cw.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cw.z);
         uint32_t R[NE][ND], N[NE][ND];
         apm_nfa_init<K>(R); // cell(0, y) = y
         int x = 0;
-        // (two bytes per trip: the columns swap roles instead of being copied, and both class numbers come with one LDS read
-        // -- a scalar after readfirstlane, so the T words' address is the lane's alone.  Fully unrolled over 32 bytes with
-        // scalar class loads the loop measured slower, 9.8 against 9.0 ms per GiB, and so did T words kept in registers
-        // for <= 4 classes, picked by uniform selects: 10.9)
+        // (two bytes per trip: the columns swap roles instead of being copied.  Fully unrolled over 32 bytes the loop
+        // measured slower, 9.8 against 9.0 ms per GiB, and so did T words kept in registers for <= 4 classes, picked by
+        // uniform selects: 10.9)
         for (; x + 1 < m; x += 2) {
-            const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint16_t *>(cls + x));
-            step(R, N, x, m, c2 & 0xffu);
-            step(N, R, x + 1, m, c2 >> 8);
+            const uint32_t c2 = (uint32_t)clo & 0xffu;
+            clo = (clo >> 8) | (chi << 56);
+            chi >>= 8;
+            step(R, N, x, m, c2 & 0xfu);
+            step(N, R, x + 1, m, c2 >> 4);
         }
-        if (x < m) step(R, N, x, m, (uint32_t)__builtin_amdgcn_readfirstlane((int)cls[x]));
+        if (x < m) step(R, N, x, m, (uint32_t)clo & 0xfu);
         const uint32_t fin = (m & 1) ? N[K][B] : R[K][B];
-        // windows j0 + b that are full windows of this shard's range
-        const int64_t je_p = min(a.je, a.nrel - m + 1);
-        const int64_t lo = a.jb - j0, hi = je_p - j0; // valid bits: [lo, hi)
-        uint32_t valid = 0xffffffffu;
-        if (lo > 0) valid = lo >= 32 ? 0u : (valid << (int)lo);
-        if (hi < 32) valid = hi <= 0 ? 0u : (valid & ((1u << (int)hi) - 1u));
+        // windows j0 + b that are full windows of this shard's range: bits [lo_rel, hi)
+        const int hi = min(je_rel, end_rel - m);
+        uint32_t valid = lo_mask;
+        if (hi < 32) valid = hi <= 0 ? 0u : (valid & ((1u << hi) - 1u));
         uint32_t hits = fin & valid;
         if (a.pos.out)
             for (uint32_t h = hits; h; h &= h - 1u) apm_push_pos(a.pos, j0 + (int64_t)__builtin_ctz(h));
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(APM_BLOCK) void apm_nfa_kernel(ApmNfaArgs a) {
     }
 }
 
-size_t apm_nfa_lds_bytes(const ApmNfaArgs &a) { return (size_t)a.n_classes * 2 * APM_BLOCK * 4 + (size_t)((a.n_pats + 3) & ~3) * 4 + (size_t)a.cls_len + 16; }
+size_t apm_nfa_lds_bytes(const ApmNfaArgs &a) { return (size_t)a.n_classes * 2 * APM_BLOCK * 4 + (size_t)((a.n_pats + 3) & ~3) * 4 + 16; }
 
 hipError_t apm_launch_nfa(const ApmNfaArgs &a, hipStream_t s) {
     const int64_t span = a.je - a.tile0;

@@ -811,7 +811,7 @@ int build_plan(apm_ctx *ctx) {
             ctx->tiled.push_back(std::move(L));
         }
     }
-    // ---- NFA launches: <= 16 byte classes, <= 512 patterns and 16 KiB of class numbers per launch ----
+    // ---- NFA launches: <= 16 byte classes and <= 512 patterns per launch ----
     {
         std::vector<int> idx;
         for (int i = 0; i < P; ++i) if (ctx->pats[i].kernel == APM_KERNEL_NFA) idx.push_back(i);
@@ -833,8 +833,11 @@ int build_plan(apm_ctx *ctx) {
                 d.m = (uint32_t)pi.m;
                 d.index = (uint32_t)idx[pos];
                 d.byte_off = (uint32_t)L.bytes.size();
-                for (unsigned char c : pi.bytes) L.bytes.push_back((uint8_t)cls_of[c]);
-                while (L.bytes.size() % 32) L.bytes.push_back(0); // (32 bytes per pattern: the kernel reads them with two scalar 16-byte loads)
+                // 16 bytes per pattern: the class number of pattern byte x in nibble x (the kernel reads them with one
+                // scalar 16-byte load and shifts the next one out per column)
+                L.bytes.resize(L.bytes.size() + 16, 0);
+                for (size_t x = 0; x < pi.bytes.size(); ++x)
+                    L.bytes[d.byte_off + x / 2] |= (uint8_t)(cls_of[(unsigned char)pi.bytes[x]] << (4 * (x & 1)));
                 L.descs.push_back(d);
                 L.m_max = std::max(L.m_max, pi.m);
                 L.m_min = L.m_min ? std::min(L.m_min, pi.m) : pi.m;
