@@ -45,6 +45,18 @@ __global__ void apm_popcount_kernel(const uint32_t *w, unsigned long long n, uns
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
 }
 
+// the same over the rows of the listed blocks, plus the entries of the candidate list's regions (the statistics of a pass
+// that ran with the list: the other rows were never written)
+__global__ void apm_popcount_listed_kernel(const uint32_t *w, const uint32_t *blist, const uint32_t *n_listed, const uint32_t *clist_cnt, int regions, unsigned long long *sum) {
+    unsigned long long acc = 0;
+    const unsigned long long n = (unsigned long long)*n_listed * 64ull, t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long i = t0; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        acc += (unsigned long long)__popc(w[(unsigned long long)blist[i >> 6] * 64ull + (i & 63ull)]);
+    for (unsigned long long i = t0; i < (unsigned long long)regions; i += (unsigned long long)gridDim.x * blockDim.x) acc += clist_cnt[i];
+    for (int d = 32; d; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
+}
+
 // k >= m: every window start matches (the DP never exceeds m); one launch adds the window count to all of them
 __global__ void apm_add_const_kernel(unsigned long long *counts, const int *idx, int n, unsigned long long v) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -184,6 +196,11 @@ struct DeviceState {
     uint32_t *d_blist = nullptr;               // the sieve's list of non-empty blocks (one dword per 4 KiB block at most)
     size_t blist_cap = 0;
     int sieve_epoch = 0;                       // which of the two list counters the next sieve launch counts in
+    uint32_t *d_clist = nullptr;               // the sieve's candidate list (ApmSieve2Args::clist) and its per-region counts
+    uint32_t *d_clist_cnt = nullptr;
+    size_t clist_cap = 0;                      // entries allocated
+    int last_clist_regions = 0;                // the last sieve pass ran with the list: its regions and block-list counter (statistics)
+    const uint32_t *last_blist_ctr = nullptr;
     unsigned long long *d_stats = nullptr;     // 8 counters (statistics kernel; measurement build: verify counters)
     bool last_fused = false;                   // the last call used the fused form of the pipeline
     hipEvent_t ev_start = nullptr, ev_kstart = nullptr, ev_mstart = nullptr, ev_mstop = nullptr, ev_stop = nullptr;
@@ -1390,6 +1407,29 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 ds.blist_cap = (size_t)n_mask_blocks + 64;
             }
             static const int blist_env = getenv("APM_SIEVE_BLIST") ? atoi(getenv("APM_SIEVE_BLIST")) : 1; // (A/B aid: 0 = the verify launches walk every mask row)
+            // candidate list of the code-filter form: 32 entries allocated per 4 KiB block (half the bytes of the mask rows).
+            // APM_SIEVE_CLIST=0 turns it off (A/B aid); APM_CLIST_REGION_CAP=n (1..64) shrinks every region to n entries (the
+            // tests force the overflow path with it)
+            static const int clist_env = getenv("APM_SIEVE_CLIST") ? atoi(getenv("APM_SIEVE_CLIST")) : 1;
+            static const int clist_cap_env = getenv("APM_CLIST_REGION_CAP") ? std::max(1, std::min(64, atoi(getenv("APM_CLIST_REGION_CAP")))) : 0;
+            constexpr int clist_per_block = 32;
+            constexpr int kClistMaxRegions = 4096;
+            if (clist_env && blist_env) {
+                const size_t want = (size_t)n_mask_blocks * (size_t)clist_per_block + (size_t)kClistMaxRegions * 64;
+                if (ds.clist_cap < want) {
+                    if (ds.d_clist) {
+                        HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+                        HIP_TRY(ctx, hipFree(ds.d_clist));
+                    }
+                    ds.d_clist = nullptr;
+                    ds.clist_cap = 0;
+                    HIP_TRY(ctx, hipMalloc((void **)&ds.d_clist, want * 4));
+                    ds.clist_cap = want;
+                }
+                if (!ds.d_clist_cnt) HIP_TRY(ctx, hipMalloc((void **)&ds.d_clist_cnt, (size_t)kClistMaxRegions * 4));
+            }
+            int clist_regions = 0;       // of the pass in hand (0: no list kept)
+            uint32_t clist_region_cap = 0;
             ds.last_mask_blocks = n_mask_blocks;
             // one sieve pass: the set's shared bitmap (v < 0), or launch v's own bitmap with its code filter
             const uint32_t *blist_ctr = nullptr; // the list counter of the pass in hand (NULL: no list kept)
@@ -1428,6 +1468,19 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                     sv.blist_ctr_next = APM_BLIST_CTR(ds.d_work, (ds.sieve_epoch + 1) & 1);
                     blist_ctr = sv.blist_ctr;
                 }
+                clist_regions = 0;
+                if (use_blist && clist_env) {
+                    const int regions = apm_sieve2cf_blocks(sv, ds.n_cu);
+                    if (regions >= 1 && regions <= kClistMaxRegions) {
+                        clist_regions = regions;
+                        clist_region_cap = clist_cap_env ? (uint32_t)clist_cap_env : (uint32_t)std::max<int64_t>(64, n_mask_blocks * clist_per_block / regions);
+                        sv.clist = ds.d_clist;
+                        sv.clist_cnt = ds.d_clist_cnt;
+                        sv.clist_cap = clist_region_cap;
+                    }
+                }
+                ds.last_clist_regions = clist_regions;
+                ds.last_blist_ctr = blist_ctr;
                 HIP_TRY(ctx, apm_launch_sieve2(sv, ds.n_cu, ds.stream));
                 if (use_blist) ++ds.sieve_epoch; // (a launch that did not run leaves its counter set as it was: still zero)
                 return note_launch(ctx, ds, "sieve");
@@ -1466,6 +1519,17 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 if (blist_ctr) {
                     va.blist = ds.d_blist;
                     va.blist_ctr = blist_ctr;
+                }
+                if (clist_regions) {
+                    va.clist = ds.d_clist;
+                    va.clist_cnt = ds.d_clist_cnt;
+                    va.clist_cap = clist_region_cap;
+                    va.clist_regions = clist_regions;
+                    // (8: with 1 a planted occurrence's nominations scatter over as many waves, with 64 one wave walks two
+                    // occurrences of its region one after the other -- 0.06 against 0.037 ms on sparse sets of long patterns,
+                    // profiles/r03/clist_ab.txt; APM_CLIST_MIN_BATCH overrides, A/B aid)
+                    static const int min_batch_env = getenv("APM_CLIST_MIN_BATCH") ? std::max(1, std::min(64, atoi(getenv("APM_CLIST_MIN_BATCH")))) : 8;
+                    va.clist_min_batch = min_batch_env;
                 }
                 va.tile0 = p_lo;
                 va.n_mask_blocks = n_mask_blocks;
@@ -2113,6 +2177,8 @@ void apm_destroy(apm_ctx *ctx) {
         if (ds.d_stats) hipFree(ds.d_stats);
         if (ds.d_work) hipFree(ds.d_work);
         if (ds.d_blist) hipFree(ds.d_blist);
+        if (ds.d_clist) hipFree(ds.d_clist);
+        if (ds.d_clist_cnt) hipFree(ds.d_clist_cnt);
         for (hipEvent_t e : ds.ev_stage) if (e) hipEventDestroy(e);
         for (hipEvent_t e : ds.ev_launch) if (e) hipEventDestroy(e);
         for (hipEvent_t e : {ds.ev_start, ds.ev_kstart, ds.ev_mstart, ds.ev_mstop, ds.ev_stop}) if (e) hipEventDestroy(e);
@@ -2513,7 +2579,10 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
         if (!ds.d_stats) HIP_TRY(ctx, hipMalloc((void **)&ds.d_stats, APM_STATS_BYTES));
         unsigned long long *d_sum = ds.d_stats + 7;
         HIP_TRY(ctx, hipMemsetAsync(d_sum, 0, 8, ds.stream));
-        hipLaunchKernelGGL(apm_popcount_kernel, dim3(1024), dim3(256), 0, ds.stream, ds.d_masks, (unsigned long long)ds.last_mask_blocks * 64ull, d_sum);
+        if (ds.last_clist_regions)
+            hipLaunchKernelGGL(apm_popcount_listed_kernel, dim3(1024), dim3(256), 0, ds.stream, ds.d_masks, ds.d_blist, ds.last_blist_ctr, ds.d_clist_cnt, ds.last_clist_regions, d_sum);
+        else
+            hipLaunchKernelGGL(apm_popcount_kernel, dim3(1024), dim3(256), 0, ds.stream, ds.d_masks, (unsigned long long)ds.last_mask_blocks * 64ull, d_sum);
         unsigned long long h = 0;
         HIP_TRY(ctx, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, ds.stream));
         HIP_TRY(ctx, hipStreamSynchronize(ds.stream));

@@ -40,6 +40,17 @@ struct ApmSieve2Args {
        between (launch i counts in set i & 1 and zeroes the other for launch i + 1 on the same stream). */
     uint32_t *blist;
     uint32_t *blist_ctr, *blist_ctr_next;
+    /* CANDIDATE LIST (code-filter form; NULL: masks and block list only): what survives the filter is a few positions per
+       block (cfg3: 6.5 of 2048, cfg5: 0.04), so the wave appends them as 32-bit entries (relative position / 2, what the
+       verify launch forms out of a mask bit) to its WORKGROUP's region of the list -- region g = entries
+       [g * clist_cap, g * clist_cap + clist_cnt[g]), filled through a counter in LDS, no global atomics -- instead of
+       storing a 256-byte mask row per block: 1/10 of the write traffic on cfg3, and the verify launch neither reads the
+       rows nor picks the bits out of them.  A block whose entries no longer fit its region keeps the old hand-over for
+       what is left of it (mask row + block list): nothing is lost, whatever the density.  The workgroups of a launch walk
+       the text interleaved, so the regions fill evenly wherever the candidates cluster. */
+    uint32_t *clist;
+    uint32_t *clist_cnt;        /* one per scanning workgroup, written when the workgroup ends */
+    uint32_t clist_cap;         /* entries per region */
     int n_main_blocks;          /* set by the launcher: scanning workgroups */
     int n_tail;                 /* extra workgroups, one per pattern with truncated tail windows (they run beside the scan) */
     ApmTailArgs tail;
@@ -63,6 +74,7 @@ struct ApmSieve2Args {
 };
 #define APM_CF_WAVE_BYTES 1552  /* per wave: code strip 260 dwords | survivor masks 64 dwords | hit ring 128 x u16 */
 int apm_sieve2cf_geometry(int cf_len, int *threads); /* workgroups per CU; *threads = workgroup size (0: does not fit) */
+int apm_sieve2cf_blocks(const ApmSieve2Args &a, int n_cu); /* scanning workgroups the code-filter form will launch = regions of the candidate list */
 
 struct ApmVerifyArgs {
     const uint8_t *text;        /* 16-byte aligned */
@@ -93,6 +105,11 @@ struct ApmVerifyArgs {
     const uint32_t *masks;      /* see ApmSieve2Args */
     const uint32_t *blist;      /* see ApmSieve2Args; NULL: every block 0 .. n_mask_blocks - 1 */
     const uint32_t *blist_ctr;  /* entries of blist */
+    const uint32_t *clist;      /* see ApmSieve2Args (NULL: none): the candidates come from the list's regions, then from the rows of the listed blocks */
+    const uint32_t *clist_cnt;
+    uint32_t clist_cap;
+    int clist_regions;
+    int clist_min_batch;        /* 1..64: a short region is cut into batches of at least this many entries (see apm_verify_body) */
     int64_t tile0;              /* relative position of block 0 */
     int64_t n_mask_blocks;      /* 4 KiB blocks the sieve wrote masks for */
     int n_blocks;               /* set by the launcher */

@@ -86,6 +86,9 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
     for (int i = tid; i < 2048; i += THREADS) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
     if constexpr (CF)
         for (int i = tid; i < (a.cf_len >> 4); i += THREADS) reinterpret_cast<uint4 *>(smem + 32768)[i] = a.cf_image[i];
+    // candidate list (ApmSieve2Args::clist): entries reserved in the workgroup's region | the first reservation that did not fit
+    uint32_t *cl_ctr = reinterpret_cast<uint32_t *>(smem + 32768 + (CF ? a.cf_len + (THREADS / 64) * APM_CF_WAVE_BYTES : 0));
+    if (CF && tid == 0) { cl_ctr[0] = 0u; cl_ctr[1] = 0xffffffffu; }
     __syncthreads();
     const int64_t W = (int64_t)a.n_main_blocks * (THREADS / 64);
     const int64_t nch = a.nchunks;
@@ -274,12 +277,37 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
             const uint32_t sc[4] = {s0, s1, s2, s3};
             hm = cf_filter(hm, sc, s4);
         }
-        a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = hm;
-        if constexpr (CF) { // (without the filter nearly every block has hits: no list)
-            if (a.blist && __builtin_amdgcn_ballot_w64(hm != 0u)) {
+        if constexpr (CF) {
+            if (a.clist) { // the survivors leave as list entries, one round per bit of the fullest lane
+                const uint32_t e0 = (uint32_t)((a.tile0 + (c >> 2) * 4096) >> 1) + 8u * (uint32_t)lane;
+                uint32_t *region = a.clist + (size_t)blockIdx.x * a.clist_cap;
+                for (;;) {
+                    const bool has = hm != 0u;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(has);
+                    if (!mask) break;
+                    const uint32_t n = (uint32_t)__builtin_popcountll(mask);
+                    uint32_t base = 0;
+                    if (lane == 0) base = __hip_atomic_fetch_add(&cl_ctr[0], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base + n > a.clist_cap) { // region full: the reservations before this one are the region's entries
+                        if (lane == 0) __hip_atomic_fetch_min(&cl_ctr[1], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        break;
+                    }
+                    const uint32_t t = has ? (uint32_t)__builtin_ctz(hm) : 0u;
+                    hm &= hm - 1u;
+                    if (has)
+                        region[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = e0 + 512u * (t >> 3) + (t & 7u);
+                }
+            }
+            // the mask row (all of it without a list, what did not fit with one) and the block's entry in the block list
+            const bool any = __builtin_amdgcn_ballot_w64(hm != 0u) != 0ull;
+            if (!a.clist || any) a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = hm;
+            if (a.blist && any) {
                 if ((uint32_t)lane == bl_n) bl_pend = (uint32_t)(c >> 2);
                 if (++bl_n == 64u) bl_flush();
             }
+        } else {
+            a.masks[(size_t)(c >> 2) * 64 + (size_t)lane] = hm; // (without the filter nearly every block has hits: no list)
         }
     }
     if constexpr (CF) {
@@ -303,6 +331,7 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
             if (tid == 0 && total) *gbase = __hip_atomic_fetch_add(a.blist_ctr, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if ((uint32_t)lane < bl_n) a.blist[*gbase + before + (uint32_t)lane] = bl_pend;
+            if (a.clist && tid == 0) a.clist_cnt[blockIdx.x] = cl_ctr[0] < cl_ctr[1] ? cl_ctr[0] : cl_ctr[1]; // (behind the barrier: every wave has made its reservations)
         }
     }
 }
@@ -370,7 +399,7 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve8_kernel(ApmSiev
 }
 
 static size_t apm_sieve2cf_lds_bytes(int cf_len, int threads) {
-    return (size_t)32768 + (size_t)cf_len + (size_t)(threads / 64) * APM_CF_WAVE_BYTES;
+    return (size_t)32768 + (size_t)cf_len + (size_t)(threads / 64) * APM_CF_WAVE_BYTES + 16; // (... | the candidate list's two counters)
 }
 
 // workgroup size (a multiple of 64) and workgroups per CU that put the most waves on a CU for this code-filter image
@@ -402,6 +431,13 @@ int apm_sieve2cf_geometry(int cf_len, int *threads) {
     return best_blocks;
 }
 
+int apm_sieve2cf_blocks(const ApmSieve2Args &a, int n_cu) {
+    const int wpb = a.cf_threads / 64;
+    if (a.nchunks <= 0 || wpb < 1 || a.cf_blocks_per_cu < 1) return 0;
+    const int64_t want = (a.nchunks + 4 * wpb - 1) / (4 * wpb), cap = (int64_t)n_cu * a.cf_blocks_per_cu;
+    return (int)(want < cap ? want : cap);
+}
+
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
     if (a.nchunks <= 0) return hipSuccess;
     ApmSieve2Args args = a;
@@ -410,12 +446,11 @@ hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
 #endif
     void *kargs[] = {&args};
     if (a.stride != 8 && a.cf_image) { // the code-filter form
-        const int threads = a.cf_threads, wpb = threads / 64;
+        const int threads = a.cf_threads;
         if (threads < 128 || threads > 1024 || (threads & 63) || a.cf_blocks_per_cu < 1) return hipErrorInvalidValue;
         const size_t lds = apm_sieve2cf_lds_bytes(a.cf_len, threads);
-        const int64_t want = (a.nchunks + 4 * wpb - 1) / (4 * wpb);
-        const int64_t cap = (int64_t)n_cu * a.cf_blocks_per_cu;
-        const int64_t nb = want < cap ? want : cap;
+        const int64_t nb = apm_sieve2cf_blocks(a, n_cu);
+        if (a.clist && (!a.blist || !a.clist_cnt || a.clist_cap < 1u)) return hipErrorInvalidValue; // (what does not fit a region leaves through the block list)
         args.n_main_blocks = (int)nb;
         if (lds > 48 * 1024) apm_ensure_max_lds((const void *)apm_sieve2cf_kernel); // (per device: the geometry query ran on one)
         return hipLaunchKernel((const void *)apm_sieve2cf_kernel, dim3((unsigned)(nb + a.n_tail)), dim3((unsigned)threads), kargs, lds, s);
@@ -700,7 +735,7 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     // 4 KiB blocks in all; with a block list (ApmVerifyArgs::blist) only the listed ones: entry b of the list is the block
     // -- when the list is short: with most blocks on it (cfg3) the walk over all rows is the shorter chain of loads
     const uint32_t n_listed = (!FUSED && a.blist != nullptr) ? *a.blist_ctr : 0xffffffffu;
-    const bool listed = n_listed < (uint32_t)a.n_mask_blocks / 4u;
+    const bool listed = n_listed < (uint32_t)a.n_mask_blocks / 4u || (!FUSED && a.clist != nullptr); // (with a candidate list only the listed blocks have rows at all)
     const uint32_t NB = FUSED ? (uint32_t)((sv->nchunks + 3) >> 2) : (listed ? n_listed : (uint32_t)a.n_mask_blocks);
     // blocks per chunk: a short list is dealt block by block (cfg5: 10 K listed blocks for 4 K waves -- with chunks of 8 most
     // waves got none and the rest walked theirs one load after the other: 0.072 ms against 0.036)
@@ -880,8 +915,56 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
         }
         return out;
     };
+    // CANDIDATE LIST (ApmVerifyArgs::clist) in front of the rows: region g's batches of 64 entries are dealt statically to the
+    // waves g, g + R, g + 2R, ... (R regions; fewer waves than regions: wave w takes regions w, w + W, ... whole) -- the
+    // regions of a sieve launch fill evenly (its workgroups walk the text interleaved), so there is nothing to balance
+    // A short region is cut into as many batches as it has waves (cfg5: 40 entries for 16 waves): one wave working a
+    // dense batch alone walks the longest key list among 64 lanes, a chain of dependent gathers, while the others idle.
+    bool cl_on = false;                                  // wave-uniform, like the rest
+    uint32_t cl_r = 0, cl_rstep = 0, cl_b = 0, cl_bstep = 1, cl_n = 0, cl_bs = 64;
+    if constexpr (!FUSED && !SAMPLED) {
+        if (a.clist) {
+            const uint32_t R = (uint32_t)a.clist_regions, Wv = (uint32_t)gridDim.x * (uint32_t)(THREADS / 64);
+            if (Wv >= R) {
+                const uint32_t wpr = Wv / R;
+                cl_on = my_wave < wpr * R;
+                cl_r = my_wave % R;
+                cl_rstep = R; // (one region only)
+                cl_b = my_wave / R;
+                cl_bstep = wpr;
+            } else {
+                cl_on = my_wave < R;
+                cl_r = my_wave;
+                cl_rstep = Wv;
+            }
+            if (cl_on) {
+                cl_n = a.clist_cnt[cl_r];
+                if (Wv >= R) {
+                    const uint32_t per_wave = (cl_n + cl_bstep - 1u) / cl_bstep;
+                    const uint32_t lo = (uint32_t)a.clist_min_batch;
+                    cl_bs = per_wave >= 64u ? 64u : (per_wave < lo ? lo : per_wave);
+                }
+            }
+        }
+    }
     // the next batch: up to 64 positions (in units of STEP bytes); false once the wave's run is exhausted
     auto next_cand = [&](uint32_t &q, bool &hv) __attribute__((always_inline)) -> bool {
+        if constexpr (!FUSED && !SAMPLED) {
+            while (cl_on) {
+                const uint32_t o = cl_b * cl_bs;
+                if (o < cl_n) {
+                    const uint32_t nb = cl_n - o < cl_bs ? cl_n - o : cl_bs;
+                    hv = (uint32_t)lane < nb;
+                    q = hv ? a.clist[(size_t)cl_r * a.clist_cap + o + (uint32_t)lane] : 0u;
+                    cl_b += cl_bstep;
+                    return true;
+                }
+                cl_r += cl_rstep;
+                cl_b = 0; // (whole regions from here on: cl_bs is 64)
+                if (cl_r >= (uint32_t)a.clist_regions) { cl_on = false; break; }
+                cl_n = a.clist_cnt[cl_r];
+            }
+        }
         while (qcount < 64u) {
             if (!__builtin_amdgcn_ballot_w64(hm != 0u)) { // block done: take the prefetched masks of the next one
                 if constexpr (FUSED) { // ... or sieve the wave's next block

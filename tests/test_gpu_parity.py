@@ -1127,7 +1127,10 @@ print(json.dumps(out))
                                  {"APM_SIEVE": "0"}, {"APM_SIEVE": "0", "APM_FILTER_STREAM": "2"},
                                  {"APM_FUSED": "1"},          # sieve + verify in one kernel for every sieved set (default: sampled sets only)
                                  {"APM_FUSED": "0"},          # ... for none
-                                 {"APM_SIEVE_CF": "0"}],      # the sieve without its second stage (the code filter)
+                                 {"APM_SIEVE_CF": "0"},       # the sieve without its second stage (the code filter)
+                                 {"APM_SIEVE_CLIST": "0"},    # the code filter's survivors handed over as mask rows + block list
+                                 {"APM_CLIST_REGION_CAP": "1"},   # candidate-list regions of one / five entries: what does not fit leaves
+                                 {"APM_CLIST_REGION_CAP": "5"}],  # through the rows of its block (list and rows mixed)
                          ids=lambda e: ",".join("%s=%s" % (k[4:], v) for k, v in e.items()) or "default")
 def test_every_filter_kernel_form_agrees_with_oracle(env):
     """The BANDED path picks between the LDS-tile kernel (LDS-DMA or register-staged) and the wave-autonomous

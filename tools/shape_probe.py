@@ -13,6 +13,8 @@ text = torch.empty(n + 16, dtype=torch.uint8, device="cuda:0"); text[:n] = host.
 rnd = random.Random(3)
 shapes = [(32, 16, 30, 1), (32, 16, 128, 1), (32, 24, 64, 2), (32, 64, 128, 5), (32, 64, 128, 6), (32, 64, 128, 7), (32, 40, 128, 4),
           (32, 129, 256, 3), (32, 129, 256, 7), (32, 12, 15, 3), (256, 100, 100, 3), (64, 16, 16, 2)]
+if os.environ.get("SHAPE_SET") == "sparse":  # few candidates, long DPs
+    shapes = [(32, 64, 128, 5), (32, 40, 128, 4), (32, 24, 64, 2)]
 if os.environ.get("SHAPE_SET") == "long":   # long, loose patterns: full-DP kernels (use SHAPE_MIB=16)
     shapes = [(8, 200, 256, 40), (4, 300, 400, 3), (4, 300, 500, 100), (2, 600, 700, 10), (2, 900, 1024, 10), (2, 1300, 1300, 5), (1, 2048, 2048, 10), (1, 4096, 4096, 10)]
 forced = os.environ.get("SHAPE_KERNEL")
