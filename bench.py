@@ -286,7 +286,8 @@ def main():
 
         # A region of K steps of this path is a few milliseconds (K = 20: 8 ms), and one clock ramp or one descheduled host
         # thread decides it.  The region is therefore timed REPEATEDLY -- every repeat is exactly K steps, bracketed as the
-        # contract says -- until 0.25 s have been spent (at least 3, at most 15 repeats; a FIRST region of >= 50 ms stands alone), and the MEDIAN
+        # contract says -- until 0.25 s have been spent (at least 3, at most 15 repeats; only a FIRST region of >= 1 s stands alone:
+        # one of 75 ms -- 250 steps of cfg2, six times its kernel time -- was a host stall, round 3), and the MEDIAN
         # region is reported; all of them are listed in `timed_regions_ms_per_step`.  (All ranks take the same decisions:
         # the elapsed time they see is the all-reduced maximum.)
         regions = []
@@ -295,7 +296,7 @@ def main():
             el, ev_ms_r, counts = timed_region()
             regions.append((el, ev_ms_r))
             spent += el
-            if (len(regions) == 1 and el >= 0.05) or (spent >= 0.25 and len(regions) >= 3) or len(regions) >= 15:
+            if (len(regions) == 1 and el >= 1.0) or (spent >= 0.25 and len(regions) >= 3) or len(regions) >= 15:
                 break
         regions.sort()
         elapsed, ev_ms = regions[(len(regions) - 1) // 2]
@@ -386,7 +387,7 @@ def main():
         if exact_k0 is not None:
             rec["counts_equal_closed_form_k0"] = exact_k0
         if ctx.stat("sieve_on"):
-            rec["sieve"] = {key: ctx.stat(key) for key in ("sieve_rate", "sieve_mask_bytes", "sieve_candidates",
+            rec["sieve"] = {key: ctx.stat(key) for key in ("sieve_rate", "sieve_clist", "sieve_mask_bytes", "sieve_candidates",
                                                             "sieve_stride", "sieve_fused", "verify_launches", "verify_image_bytes", "verify_blocks_per_cu", "verify_threads")}
 
         # full-DP kernel variants, reported under their own label (cells really evaluated)
@@ -498,7 +499,7 @@ def main():
         "event_ms_per_step": head["event_ms_per_step"],
         "timed_regions": head["timed_regions"], "timed_regions_ms_per_step": head["timed_regions_ms_per_step"],
         "timing_note": "ms_per_step / value = the MEDIAN of `timed_regions` regions of exactly `steps` steps each (every region bracketed "
-                       "by barrier + synchronize; repeated until 0.25 s are spent when one region is shorter than 50 ms)",
+                       "by barrier + synchronize; at least 3 regions and 0.25 s unless the first region alone takes 1 s)",
         "roofline": head["roofline"],
     }
     for key in ("counts_equal_bitpar", "counts_equal_closed_form_k0", "sieve", "variants"):

@@ -210,8 +210,9 @@ int apm_get_timing(const apm_ctx *ctx, apm_timing *out);
 int apm_get_launch_times(const apm_ctx *ctx, int max, double *ms, const char **labels);
 /* Named statistics of the plan / the last counting call on device 0 (introspection for benchmarks and DESIGN.md):
  * "sieve_on", "sieve_stride" (1 or 8), "sieve_rate" (expected hits per lookup), "sieve_fused" (last call used the fused
- * kernel), "sieve_mask_bytes" (hit masks the last call's sieve wrote), "sieve_candidates" (their set bits: runs a popcount
- * kernel and synchronises with the stream), "verify_launches", "verify_image_bytes", "verify_blocks_per_cu",
+ * kernel), "sieve_clist" (the last sieve pass handed its survivors over as a candidate list), "sieve_mask_bytes" (bytes of that
+ * hand-over: list entries + the mask rows of blocks that overflowed, or all mask rows without a list; synchronises),
+ * "sieve_candidates" (the candidates handed over: runs a reduction kernel and synchronises with the stream), "verify_launches", "verify_image_bytes", "verify_blocks_per_cu",
  * "verify_threads".  Unknown names: APM_ERR_INVALID. */
 int apm_get_stat(const apm_ctx *ctx, const char *name, double *value);
 /* Kernel variant AUTO (or the forced variant) resolves to for pattern i. */

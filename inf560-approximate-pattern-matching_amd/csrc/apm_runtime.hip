@@ -1730,7 +1730,7 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
         { const int nrc = note_launch(ctx, ds, (L.kind == APM_KERNEL_BITPAR ? "bitpar" : "wavefront")); if (nrc) return nrc; }
     }
     ds.last_fused = fused_run;
-    if (!sieve_run) ds.last_mask_blocks = 0;
+    if (!sieve_run) { ds.last_mask_blocks = 0; ds.last_clist_regions = 0; }
     int rc = launch_generic_group(ctx, ds, ctx->longs, ds.d_long_descs, 2, d_text, avail, jb, je, nrel, d_counts, sink);
     if (rc) return rc;
     if (ctx->timing_on) HIP_TRY(ctx, hipEventRecord(ds.ev_mstop, ds.stream));
@@ -2561,7 +2561,22 @@ int apm_get_stat(const apm_ctx *cctx, const char *name, double *value) {
     if (n == "sieve_weak_frac") { *value = ctx->sieve.weak_frac; return APM_OK; }
     if (n == "sieve_cf_bytes") { *value = ctx->sieve.per_launch_sieve ? (double)ctx->sieve.launches[0].cf_image.size() : 0.0; return APM_OK; }
     if (n == "sieve_stride") { *value = ctx->sieve.on ? (double)ctx->sieve.stride : 0.0; return APM_OK; }
-    if (n == "sieve_mask_bytes") { *value = (double)ds.last_mask_blocks * 256.0; return APM_OK; }
+    if (n == "sieve_clist") { *value = ds.last_clist_regions ? 1.0 : 0.0; return APM_OK; }
+    if (n == "sieve_mask_bytes") { // what the last sieve pass handed over: mask rows, or list entries + the rows of the overflow blocks
+        *value = (double)ds.last_mask_blocks * 256.0;
+        if (ds.last_clist_regions && ds.last_mask_blocks > 0) {
+            HIP_TRY(ctx, hipSetDevice(ds.dev));
+            std::vector<uint32_t> cnt((size_t)ds.last_clist_regions);
+            uint32_t listed = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(cnt.data(), ds.d_clist_cnt, cnt.size() * 4, hipMemcpyDeviceToHost, ds.stream));
+            HIP_TRY(ctx, hipMemcpyAsync(&listed, ds.last_blist_ctr, 4, hipMemcpyDeviceToHost, ds.stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+            double entries = 0;
+            for (uint32_t c : cnt) entries += (double)c;
+            *value = 4.0 * entries + 256.0 * (double)listed;
+        }
+        return APM_OK;
+    }
     if (n == "verify_launches") { *value = (double)ctx->sieve.launches.size(); return APM_OK; }
     if (n == "verify_image_bytes") { *value = ctx->sieve.launches.empty() ? 0.0 : (double)ctx->sieve.launches[0].image.size(); return APM_OK; }
     if (n == "verify_blocks_per_cu") { // (of the form the last call ran)

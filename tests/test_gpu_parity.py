@@ -1101,7 +1101,7 @@ for name, alphabet, n in (("dna", b"ACGT", 300000), ("prose", b"etaoin shrdlucET
         with apm.ApmContext(device=0) as ctx:
             ctx.set_patterns(pats, k)
             out["%s:%d" % (name, k)] = dict(patterns=[p.decode("latin-1") for p in pats], counts=ctx.count_buffer(bytes(text)),
-                                            kernels=[ctx.pattern_kernel(i) for i in range(len(pats))])
+                                            kernels=[ctx.pattern_kernel(i) for i in range(len(pats))], clist=ctx.stat("sieve_clist"))
     for k in (2, 3, 4):   # long pieces only (>= 15 bytes): the sampled (stride-8) sieve
         pats = []
         for m in (80, 96, 100, 128):
@@ -1155,6 +1155,12 @@ def test_every_filter_kernel_form_agrees_with_oracle(env):
             assert kern == want_kern, "BANDED wherever the pieces are long enough, the automaton for short loose patterns, else the bit-vector kernel"
         assert res["counts"] == H.oracle_counts(texts[name], pats, int(k), banded=True), (key, env)
         assert sum(res["counts"]) >= (4 if key.endswith(":long") else 5)
+    # the candidate list is the hand-over of the code-filter sieve unless a switch takes the filter, the list or the sieve away
+    with_list = [key for key, res in got.items() if res.get("clist")]
+    if any(env.get(sw) is not None for sw in ("APM_SIEVE", "APM_FUSED", "APM_SIEVE_CF", "APM_SIEVE_CLIST")):
+        assert not with_list or env.get("APM_FUSED") == "0", (env, with_list)
+    else:
+        assert with_list, env
 
 
 @pytest.mark.parametrize("m,k", [(16, 3), (20, 3), (36, 3), (50, 5), (24, 2)])
