@@ -1224,7 +1224,7 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
 // window lies in exactly one piece; what a piece reads in front of its first window start never decides a match).
 int scan_shard(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_t text_off, uint64_t text_len,
                uint64_t n_total, uint64_t own_begin, uint64_t own_end, unsigned long long *d_counts) {
-    const uint64_t lim32 = ((uint64_t)1 << 32) - 4096;
+    const uint64_t lim32 = (uint64_t)APM_SIEVE_MAX_BYTES - 4096;
     // an unaligned text pointer into a bigger buffer: start the shard's text at the 16-byte boundary in front of it (those
     // bytes are readable -- apm.h -- and lie in front of every window start of the shard, where nothing decides a match)
     const uint64_t mis = (uint64_t)(reinterpret_cast<uintptr_t>(d_text) & 15u);
@@ -1299,7 +1299,7 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
         const int64_t avail_pad = avail + (int64_t)((16u - ((reinterpret_cast<uintptr_t>(d_text) + (uintptr_t)avail) & 15u)) & 15u);
         const int64_t p_lo = std::max<int64_t>(0, jb - band) & ~(int64_t)15;
         const int64_t p_hi = std::min<int64_t>(avail, je + ctx->sieve.m_max + band);
-        if (p_hi > p_lo && avail_pad >= 16 && avail_pad < ((int64_t)1 << 32) - 4096) {
+        if (p_hi > p_lo && avail_pad >= 16 && avail_pad <= APM_SIEVE_MAX_BYTES) {
             if (!ds.d_work) {
                 HIP_TRY(ctx, hipMalloc((void **)&ds.d_work, APM_WORK_BYTES));
                 HIP_TRY(ctx, hipMemsetAsync(ds.d_work, 0, APM_WORK_BYTES, ds.stream));
@@ -1414,20 +1414,6 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
             static const int clist_cap_env = getenv("APM_CLIST_REGION_CAP") ? std::max(1, std::min(64, atoi(getenv("APM_CLIST_REGION_CAP")))) : 0;
             constexpr int clist_per_block = 32;
             constexpr int kClistMaxRegions = 4096;
-            if (clist_env && blist_env) {
-                const size_t want = (size_t)n_mask_blocks * (size_t)clist_per_block + (size_t)kClistMaxRegions * 64;
-                if (ds.clist_cap < want) {
-                    if (ds.d_clist) {
-                        HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
-                        HIP_TRY(ctx, hipFree(ds.d_clist));
-                    }
-                    ds.d_clist = nullptr;
-                    ds.clist_cap = 0;
-                    HIP_TRY(ctx, hipMalloc((void **)&ds.d_clist, want * 4));
-                    ds.clist_cap = want;
-                }
-                if (!ds.d_clist_cnt) HIP_TRY(ctx, hipMalloc((void **)&ds.d_clist_cnt, (size_t)kClistMaxRegions * 4));
-            }
             int clist_regions = 0;       // of the pass in hand (0: no list kept)
             uint32_t clist_region_cap = 0;
             ds.last_mask_blocks = n_mask_blocks;
@@ -1470,6 +1456,18 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 }
                 clist_regions = 0;
                 if (use_blist && clist_env) {
+                    const size_t want = (size_t)n_mask_blocks * (size_t)clist_per_block + (size_t)kClistMaxRegions * 64;
+                    if (ds.clist_cap < want) { // (allocated by the first pass that keeps a list: sets without the code filter never do)
+                        if (ds.d_clist) {
+                            HIP_TRY(ctx, hipStreamSynchronize(ds.stream));
+                            HIP_TRY(ctx, hipFree(ds.d_clist));
+                        }
+                        ds.d_clist = nullptr;
+                        ds.clist_cap = 0;
+                        HIP_TRY(ctx, hipMalloc((void **)&ds.d_clist, want * 4));
+                        ds.clist_cap = want;
+                    }
+                    if (!ds.d_clist_cnt) HIP_TRY(ctx, hipMalloc((void **)&ds.d_clist_cnt, (size_t)kClistMaxRegions * 4));
                     const int regions = apm_sieve2cf_blocks(sv, ds.n_cu);
                     if (regions >= 1 && regions <= kClistMaxRegions) {
                         clist_regions = regions;

@@ -72,6 +72,9 @@ struct ApmSieve2Args {
     int skip_mask;
 #endif
 };
+/* text bytes a sieve launch addresses: 32-bit offsets, and a wave loads up to 4 x (waves of the launch) chunks of 1 KiB
+   ahead of the scanned range (<= 4 x 8192 KiB) -- those offsets must not wrap */
+#define APM_SIEVE_MAX_BYTES (((int64_t)1 << 32) - ((int64_t)64 << 20))
 #define APM_CF_WAVE_BYTES 1552  /* per wave: code strip 260 dwords | survivor masks 64 dwords | hit ring 128 x u16 */
 int apm_sieve2cf_geometry(int cf_len, int *threads); /* workgroups per CU; *threads = workgroup size (0: does not fit) */
 int apm_sieve2cf_blocks(const ApmSieve2Args &a, int n_cu); /* scanning workgroups the code-filter form will launch = regions of the candidate list */

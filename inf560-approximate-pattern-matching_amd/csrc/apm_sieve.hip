@@ -96,27 +96,21 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
     // 16 bytes per lane and chunk; `tl`: the 8 bytes behind the chunk (one address for the whole wave).  Chunks behind the
     // scanned range are loaded all the same -- text or, beyond avail_pad, zeros without traffic -- because the windows of
     // the last valid chunk run into them; only their own hits are dropped.
+    // ONE buffer resource over the whole shard (< 4 GiB - 64 MiB, checked by the launcher: the offsets of the chunks a
+    // wave loads ahead, up to 4 W beyond the scanned range, do not wrap) and 32-bit offsets: a resource per chunk cost two
+    // 64-bit VALU compares per load (the scalar unit has none), ten per block.
+    const __amdgpu_buffer_rsrc_t rs_all =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
+    const uint32_t t0_32 = (uint32_t)a.tile0, lane16 = 16u * (uint32_t)lane;
     auto load_chunk = [&](int64_t cc, u32x4 &r) __attribute__((always_inline)) {
-        const int64_t g = a.tile0 + cc * 1024;
-        const int64_t lim = a.avail_pad - g;
-        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1024 ? 1024u : (uint32_t)lim);
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (lim > 0 ? g : 0), 0, (int)nrec, 0x00020000);
-        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs_all, (int)(t0_32 + (uint32_t)cc * 1024u + lane16), 0, 0);
     };
     auto load_tail = [&](int64_t cc, v2u32 &tl) __attribute__((always_inline)) { // the 8 bytes at the start of chunk cc
-        const int64_t g = a.tile0 + cc * 1024;
-        const int64_t lim = a.avail_pad - g;
-        const uint32_t nrec = lim <= 0 ? 0u : (lim > 8 ? 8u : (uint32_t)lim);
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (lim > 0 ? g : 0), 0, (int)nrec, 0x00020000);
-        tl = __builtin_amdgcn_raw_buffer_load_b64(rs, 0, 0, 0);
+        tl = __builtin_amdgcn_raw_buffer_load_b64(rs_all, (int)(t0_32 + (uint32_t)cc * 1024u), 0, 0);
     };
     // CF: the halo of the block that starts at chunk cc -- lanes 0, 1: the 32 bytes behind it, lane 2: the 16 bytes in front
     // of it, lane 3 and up: zeros (one load; the resource spans the whole shard: < 4 GiB, zeros outside, and a position in
     // front of the shard wraps to a huge offset = zeros, as for every verify path)
-    const __amdgpu_buffer_rsrc_t rs_all =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
     auto load_halo = [&](int64_t cc, u32x4 &hl) __attribute__((always_inline)) {
         const uint32_t g = (uint32_t)(a.tile0 + cc * 1024);
         const uint32_t off = lane < 2 ? g + 4096u + 16u * (uint32_t)lane : (lane == 2 ? g - 16u : 0xfffffff0u);
@@ -362,13 +356,12 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve8_kernel(ApmSiev
     __syncthreads();
     const int64_t W = (int64_t)a.n_main_blocks * (APM_SIEVE2_BLOCK / 64);
     const int64_t nch = a.nchunks;
+    // (one resource over the shard and 32-bit offsets, as in apm_sieve2_body; chunks behind the range: no load at all)
+    const __amdgpu_buffer_rsrc_t rs_all =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text), 0, (int)(uint32_t)a.avail_pad, 0x00020000);
+    const uint32_t t0_32 = (uint32_t)a.tile0, lane16 = 16u * (uint32_t)lane;
     auto load_chunk = [&](int64_t cc, u32x4 &r) __attribute__((always_inline)) {
-        const int64_t g = a.tile0 + cc * 1024;
-        const int64_t lim = cc < nch ? a.avail_pad - g : 0;
-        const uint32_t nrec = lim <= 0 ? 0u : (lim > 1024 ? 1024u : (uint32_t)lim);
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.text) + (cc < nch ? g : 0), 0, (int)nrec, 0x00020000);
-        r = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * lane, 0, 0);
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs_all, (int)(cc < nch ? t0_32 + (uint32_t)cc * 1024u + lane16 : 0xfffffff0u), 0, 0);
     };
     const uint32_t cs = (uint32_t)a.code_shift;
     auto pack4 = [&](uint32_t w4) __attribute__((always_inline)) { return apm_udot4((w4 >> cs) & 0x03030303u, 0x40100401u); };
@@ -440,6 +433,7 @@ int apm_sieve2cf_blocks(const ApmSieve2Args &a, int n_cu) {
 
 hipError_t apm_launch_sieve2(const ApmSieve2Args &a, int n_cu, hipStream_t s) {
     if (a.nchunks <= 0) return hipSuccess;
+    if (a.avail_pad > APM_SIEVE_MAX_BYTES || a.tile0 < 0) return hipErrorInvalidValue; // (32-bit offsets, the loads a wave issues ahead included)
     ApmSieve2Args args = a;
 #ifdef APM_MEASURE
     if (const char *e = getenv("APM_MEASURE_SKIP")) args.skip_mask = atoi(e);
