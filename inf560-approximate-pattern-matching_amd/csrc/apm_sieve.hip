@@ -211,6 +211,35 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
                 }
             }
         };
+#ifndef APM_CF_NOSCAN /* (A/B builds) */
+        // Where the hits go in the ring: a wave prefix sum over the lanes' hit counts (six DPP adds), then every lane writes
+        // its own hits one after the other -- a round is ctz + store, not ballot + mbcnt + popcount (cfg5: five rounds per
+        // block).  The ring is empty here and holds 128; a fuller block takes the round-by-round form below.
+        {
+            const uint32_t cnt = (uint32_t)__builtin_popcount(hm);
+            uint32_t inc = cnt; // inclusive prefix sum: within the rows of 16 lanes, then across them
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false); // row_shr:1
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false); // row_shr:2
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false); // row_shr:4
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false); // row_shr:8
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (total <= 128u) { // (wave-uniform)
+                uint32_t pos = inc - cnt; // (qt == qh == 0: the ring was drained by the block before)
+                while (__builtin_amdgcn_ballot_w64(hm != 0u)) {
+                    if (hm != 0u) {
+                        const uint32_t t = (uint32_t)__builtin_ctz(hm);
+                        hm &= hm - 1u;
+                        rq[pos & 127u] = (uint16_t)(512u * (t >> 3) + 8u * (uint32_t)lane + (t & 7u));
+                        ++pos;
+                    }
+                }
+                qt = total;
+                while (qt - qh >= 64u) { run_batch(64u); qh += 64u; }
+            }
+        }
+#endif
         while (__builtin_amdgcn_ballot_w64(hm != 0u)) {
             const bool has = hm != 0u;
             const uint32_t t = has ? (uint32_t)__builtin_ctz(hm) : 0u;
