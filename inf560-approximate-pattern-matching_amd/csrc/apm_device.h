@@ -17,6 +17,23 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 apm_as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
+// Stage n16 x 16 bytes of a launch image from global memory into LDS with FOUR loads in flight per thread: the plain
+// copy loop compiles to load, wait, store, and a 17..42 KiB image then costs a workgroup four to six memory round trips
+// one after the other -- most of an otherwise empty launch's 17 microseconds (round 3 measurement).
+__device__ __forceinline__ void apm_stage_image(uint4 *dst, const uint4 *src, int n16, int tid, int threads) {
+    for (int i = tid; i < n16; i += 4 * threads) {
+        const int i1 = i + threads, i2 = i + 2 * threads, i3 = i + 3 * threads;
+        const uint4 v0 = src[i];
+        const uint4 v1 = src[i1 < n16 ? i1 : i]; // (in range whatever n16 is; stored only when its slot exists)
+        const uint4 v2 = src[i2 < n16 ? i2 : i];
+        const uint4 v3 = src[i3 < n16 ? i3 : i];
+        dst[i] = v0;
+        if (i1 < n16) dst[i1] = v1;
+        if (i2 < n16) dst[i2] = v2;
+        if (i3 < n16) dst[i3] = v3;
+    }
+}
+
 // N dwords of bytes starting at (16-byte aligned LDS base) + off, any alignment of off:
 // N+1 aligned ds_read_b32 + N v_alignbyte -- no dependent byte loads
 template <int N>

@@ -1073,7 +1073,7 @@ void apm_stream_kernel(ApmFilterArgs a) {
     uint2 *s_queue = reinterpret_cast<uint2 *>(s_img + a.image_len) + wv * QW; // this wave's queue
     uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_img + a.image_len + 4 * QW * 8);
 
-    for (int i = tid; i < (a.image_len >> 4); i += APM_BLOCK) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
+    apm_stage_image(reinterpret_cast<uint4 *>(s_img), a.image, a.image_len >> 4, tid, APM_BLOCK);
     for (int i = tid; i < a.n_pats; i += APM_BLOCK) s_cnt[i] = 0u;
     __syncthreads(); // the only workgroup barrier before the final count flush
 

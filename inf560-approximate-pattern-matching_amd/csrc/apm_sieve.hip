@@ -83,9 +83,8 @@ __device__ __forceinline__ void apm_sieve2_body(const ApmSieve2Args &a, uint8_t 
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
-    for (int i = tid; i < 2048; i += THREADS) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
-    if constexpr (CF)
-        for (int i = tid; i < (a.cf_len >> 4); i += THREADS) reinterpret_cast<uint4 *>(smem + 32768)[i] = a.cf_image[i];
+    apm_stage_image(reinterpret_cast<uint4 *>(smem), a.bitmap, 2048, tid, THREADS);
+    if constexpr (CF) apm_stage_image(reinterpret_cast<uint4 *>(smem + 32768), a.cf_image, a.cf_len >> 4, tid, THREADS);
     // candidate list (ApmSieve2Args::clist): entries reserved in the workgroup's region | the first reservation that did not fit
     uint32_t *cl_ctr = reinterpret_cast<uint32_t *>(smem + 32768 + (CF ? a.cf_len + (THREADS / 64) * APM_CF_WAVE_BYTES : 0));
     if (CF && tid == 0) { cl_ctr[0] = 0u; cl_ctr[1] = 0xffffffffu; }
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(APM_SIEVE2_BLOCK, 8) void apm_sieve8_kernel(ApmSiev
         apm_tail_body(a.tail, (int)blockIdx.x - a.n_main_blocks, reinterpret_cast<uint4 *>(smem), tid);
         return;
     }
-    for (int i = tid; i < 512; i += APM_SIEVE2_BLOCK) reinterpret_cast<uint4 *>(smem)[i] = a.bitmap[i];
+    apm_stage_image(reinterpret_cast<uint4 *>(smem), a.bitmap, 512, tid, APM_SIEVE2_BLOCK);
     __syncthreads();
     const int64_t W = (int64_t)a.n_main_blocks * (APM_SIEVE2_BLOCK / 64);
     const int64_t nch = a.nchunks;
@@ -724,8 +723,8 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
     uint32_t *s_q = reinterpret_cast<uint32_t *>(reinterpret_cast<uint2 *>(s_cnt + ((a.n_pats + 3) & ~3)) + (THREADS / 64) * SCAP) + wv * 128; // this wave's hit queue
 
     if constexpr (FUSED && !SAMPLED)
-        for (int i = tid; i < 2048; i += THREADS) reinterpret_cast<uint4 *>(smem)[i] = sv->bitmap[i];
-    for (int i = tid; i < (a.image_len >> 4); i += THREADS) reinterpret_cast<uint4 *>(s_img)[i] = a.image[i];
+        apm_stage_image(reinterpret_cast<uint4 *>(smem), sv->bitmap, 2048, tid, THREADS);
+    apm_stage_image(reinterpret_cast<uint4 *>(s_img), a.image, a.image_len >> 4, tid, THREADS);
     for (int i = tid; i < a.n_pats; i += THREADS) s_cnt[i] = 0u;
     __syncthreads(); // the only workgroup barrier before the final count flush
 
