@@ -117,7 +117,7 @@ struct VerifyLaunch {      // one apm_verify_kernel launch: a group of patterns 
     std::vector<uint32_t> kpart;      // per key: partner offset inside the pattern | partner length << 16
     std::vector<uint32_t> pinfo;      // per pattern: {byte_off | m << 16, id of its first key}
     std::vector<uint8_t> image;       // bitmap16 | prefix | r2s | slots | kext | pattern bytes
-    int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0, o_masks = 0, o_kinfo = 0, o_pinfo = 0;
+    int o_prefix = 0, o_r2s = 0, o_slots = 0, o_kext = 0, o_pat = 0, o_masks = 0, o_kinfo = 0, o_pinfo = 0, o_rc = 0;
     int m_max = 0, m_min = 0;
     int blocks_per_cu = 0, threads = 256; // launch geometry (occupancy query, cached)
     int fused_blocks_per_cu = 0, fused_threads = 0; // the same for the fused form (threads < 0: it does not fit a CU)
@@ -610,6 +610,31 @@ int build_sieve_plan(apm_ctx *ctx, int stride) {
         V.o_pat = append(V.bytes.data(), V.bytes.size());
         V.o_kinfo = append(V.kinfo.data(), V.kinfo.size() * 4);
         V.o_pinfo = append(V.pinfo.data(), V.pinfo.size() * 4);
+        // sampled sets of up to 128 units: the operands of the fused form's REGISTER COMPARE, ready made -- per (unit, offset r
+        // of the sampled block inside its piece, half t of the lane's 16 bytes) the codes of the pattern bytes that face the
+        // lane's bytes, packed like the text, and the mask of the code bits the piece covers (apm_verify_body packs them
+        // out of the pattern bytes otherwise: five LDS reads and four packs per hit).  16 bytes per (unit, r).
+        V.o_rc = 0;
+        static const int rc_env = getenv("APM_FUSED_RC") ? atoi(getenv("APM_FUSED_RC")) : 1; // (A/B aid: 0 = pack the operands per hit)
+        if (rc_env && stride == 8 && units.size() <= 128) {
+            std::vector<uint32_t> rc(units.size() * 8 * 4, 0u);
+            for (size_t kid = 0; kid < units.size(); ++kid) {
+                const int at = (int)(kext[kid] & 0xffffu), len = (int)((kext[kid] >> 16) & 0xffu);
+                for (int r = 0; r < 8; ++r)
+                    for (int t = 0; t < 2; ++t) {
+                        const int sh8 = 8 * t - r; // lane byte i <-> pattern pool byte at - sh8 + i
+                        const int i0 = sh8 > 0 ? sh8 : 0, i1 = len + sh8 < 16 ? len + sh8 : 16;
+                        uint32_t pc = 0, mask = 0;
+                        for (int i = i0; i < i1; ++i) {
+                            pc |= (uint32_t)((V.bytes[(size_t)(at - sh8 + i)] >> S.code_shift) & 3) << (2 * i);
+                            mask |= 3u << (2 * i);
+                        }
+                        rc[((kid * 8 + (size_t)r) * 2 + (size_t)t) * 2] = pc;
+                        rc[((kid * 8 + (size_t)r) * 2 + (size_t)t) * 2 + 1] = mask;
+                    }
+            }
+            V.o_rc = append(rc.data(), rc.size() * 4);
+        }
         S.m_max = std::max(S.m_max, V.m_max);
         // the launch's own sieve pass (stride 1 with the code filter): the bitmap of ITS keys -- built like the set's below -- and
         // the code-filter tables over its key numbering.  A big set thus scans the text once per launch group, each pass
@@ -1343,6 +1368,7 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 va.o_masks = V.o_masks;
                 va.o_kinfo = V.o_kinfo;
                 va.o_pinfo = V.o_pinfo;
+                va.o_rc = V.o_rc;
                 va.kinfo = ds.verify[v].d_kinfo;
                 va.pinfo = reinterpret_cast<const uint2 *>(ds.verify[v].d_pinfo);
                 va.kpart = ds.verify[v].d_kpart;
@@ -1502,6 +1528,7 @@ int scan_shard_one(apm_ctx *ctx, DeviceState &ds, const uint8_t *d_text, uint64_
                 va.o_masks = V.o_masks;
                 va.o_kinfo = V.o_kinfo;
                 va.o_pinfo = V.o_pinfo;
+                va.o_rc = V.o_rc;
                 va.kinfo = ds.verify[v].d_kinfo;
                 va.pinfo = reinterpret_cast<const uint2 *>(ds.verify[v].d_pinfo);
                 va.kpart = ds.verify[v].d_kpart;

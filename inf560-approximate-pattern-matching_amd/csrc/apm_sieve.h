@@ -91,6 +91,7 @@ struct ApmVerifyArgs {
     const uint4 *image;
     int image_len, o_prefix, o_r2s, o_slots, o_kext, o_pat;
     int o_masks;                /* 17 x 16 bytes: entry n = n leading 0xff bytes (byte masks of a compare of n <= 16 bytes) */
+    int o_rc;                   /* 0: none; else uint2 {codes, mask} per ((unit * 8 + r) * 2 + half): the fused sampled form's register compare, precomputed (<= 128 units) */
     int o_kinfo, o_pinfo;       /* the records of the banded DP and the dedup, in the image too (round 2 kept them in global memory:
                                    with the sieve's code filter in front the DP is most of the launch, and kinfo -> pinfo -> text
                                    was a chain of three memory round trips per DP batch) */

@@ -889,7 +889,13 @@ __device__ __forceinline__ void apm_verify_body(const ApmVerifyArgs &a, const Ap
                         act = true;
                     }
                     if (!__builtin_amdgcn_ballot_w64(act)) break;
-                    if (act) {
+                    if (act && a.o_rc) { // (wave-uniform choice: small sets carry the compare's operands ready made)
+                        const uint32_t kid = cur & 2047u, rr = (cur & 0x7fffu) >> 11;
+                        const uint2 rc = reinterpret_cast<const uint2 *>(s_img + a.o_rc)[(kid * 8u + rr) * 2u + tsel];
+                        if (((rc.x ^ slo_c) & rc.y) == 0u) act = false; // may be intact: the hit stays
+                        else if (cur & 0x8000u) { act = false; out &= ~(1u << curbit); } // no key of the word fits
+                        else cur = (uint32_t)s_slots[cur >> 16] | ((cur & 0xffff0000u) + 0x10000u);
+                    } else if (act) {
                         const uint32_t kid = cur & 2047u, rr = (cur & 0x7fffu) >> 11; // (KBITS = 11: key id | offset of the block in its piece)
                         const uint32_t kx = s_kext[kid];
                         const int at = (int)(kx & 0xffffu), len = (int)((kx >> 16) & 0xffu);

@@ -1128,6 +1128,7 @@ print(json.dumps(out))
                                  {"APM_FUSED": "1"},          # sieve + verify in one kernel for every sieved set (default: sampled sets only)
                                  {"APM_FUSED": "0"},          # ... for none
                                  {"APM_SIEVE_CF": "0"},       # the sieve without its second stage (the code filter)
+                                 {"APM_FUSED_RC": "0"},       # fused sampled form: the register compare packs its operands per hit (sets of > 128 units always do)
                                  {"APM_SIEVE_CLIST": "0"},    # the code filter's survivors handed over as mask rows + block list
                                  {"APM_CLIST_REGION_CAP": "1"},   # candidate-list regions of one / five entries: what does not fit leaves
                                  {"APM_CLIST_REGION_CAP": "5"}],  # through the rows of its block (list and rows mixed)
@@ -1157,7 +1158,7 @@ def test_every_filter_kernel_form_agrees_with_oracle(env):
         assert sum(res["counts"]) >= (4 if key.endswith(":long") else 5)
     # the candidate list is the hand-over of the code-filter sieve unless a switch takes the filter, the list or the sieve away
     with_list = [key for key, res in got.items() if res.get("clist")]
-    if any(env.get(sw) is not None for sw in ("APM_SIEVE", "APM_FUSED", "APM_SIEVE_CF", "APM_SIEVE_CLIST")):
+    if any(env.get(sw) is not None for sw in ("APM_SIEVE", "APM_FUSED", "APM_SIEVE_CF", "APM_SIEVE_CLIST")):  # (APM_FUSED_RC touches sampled sets only)
         assert not with_list or env.get("APM_FUSED") == "0", (env, with_list)
     else:
         assert with_list, env
