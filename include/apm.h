@@ -122,7 +122,7 @@ const char *apm_last_error(const apm_ctx *ctx); /* ctx may be NULL: last create 
 /* Use an existing HIP stream (hipStream_t passed as void*) for all work of a
  * single-device context, e.g. torch's current stream.  NULL is HIP's null
  * (legacy default) stream; APM_STREAM_OWN restores the context's own stream.
- * The context owns device scratch (hit masks, block-distribution counters, staging) that consecutive calls reuse in
+ * The context owns device scratch (candidate list, hit masks, block-distribution counters, staging) that consecutive calls reuse in
  * stream order: when the stream is changed while earlier calls may still run, the caller orders the two streams
  * (event or synchronisation) first. */
 #define APM_STREAM_OWN ((void *)(intptr_t)-1)
